@@ -1,0 +1,498 @@
+# -*- coding: utf-8 -*-
+"""numpy restatement of the reference's own Python decoders -- TEST INFRASTRUCTURE.
+
+The reference decoders are Python 2 (``print message``, integer ``/``) and
+cannot be imported under this image's Python 3.10; this file follows them
+statement by statement with the three changes SURVEY.md section 8c lists:
+``//`` for the histogram index, explicit ragged-``np.split`` handling with the
+2017-numpy ``.size``/``.shape[0]`` semantics, Python-int field maths (numpy-1
+scalar promotion).  ``np.histogram(..., "auto")`` is numpy 2.2.6's.
+
+Pinned by the reference's known-answer vectors (tests/golden/kat.json,
+tests/test_oracle_kat.py): TS33C README pulses/gaps -> packet/fields, the two
+``docs/*.png`` bit tables, TFA tfrec line, somfy frames, mumbi/berner codes.
+
+Every class records what the reference would ``print`` in ``.prints`` and its
+debug() calls in ``.log`` instead of writing to stdout; decoded packets are
+also appended to ``.frames`` (additive, for comparisons).
+"""
+import math
+from struct import unpack
+
+import numpy as np
+
+ERROR = 1
+INFO = 2
+TRACE = 3
+
+
+class _StreamFrontEnd(object):
+    """Shared front end: TS33C/stream_decoder.py:39-110,204-220 ==
+    TFA/stream_decoder.py:59-130,201-218 (identical text, other constants)."""
+
+    def __init__(self, sample_rate, debug_level):
+        self.debug_level = debug_level
+        self.sample_rate = sample_rate
+        self.state = "idle"
+        self.chunk_id = 0
+        self.currentSymbols = np.empty(0, dtype=np.uint8)
+        self.rawBuffer = np.empty(0, dtype=np.uint8)
+        self.currentSymbolType = 0
+        self.previousSymbolType = 0
+        self.prints = []
+        self.log = []
+        self.frames = []
+
+    def debug(self, message, level=0):
+        if self.debug_level >= level:
+            self.log.append((level, message))
+
+    def _print(self, text):
+        self.prints.append(text)
+
+    @staticmethod
+    def _split_like_numpy1(symbols, reset_limit):
+        """np.array(np.split(symbols, where(symbols > limit)+1)) as numpy<1.24
+        returned it: (pieces, size, shape0).  One piece -> 2-D (1, n): size n.
+        Several pieces of equal length L -> 2-D: size = count*L.  Ragged ->
+        object array: size = count."""
+        pieces = np.split(symbols, np.ravel(np.where(symbols > reset_limit)) + 1)
+        lens = set(p.size for p in pieces)
+        if len(lens) == 1:
+            size = len(pieces) * pieces[0].size
+        else:
+            size = len(pieces)
+        return pieces, size, len(pieces)
+
+    def work(self, input_items):
+        rawChunk = input_items[0]
+        self.rawBuffer = np.append(self.rawBuffer, rawChunk)
+
+        if self.rawBuffer.size * 1e6 / self.sample_rate > self.reset_limit:
+            if (self.rawBuffer.size > 0) and ((np.sum(self.rawBuffer) > 0) or (self.currentSymbols.size > 0)):
+                self.currentSymbolType = self.rawBuffer[0]
+                self.rawBuffer = np.insert(self.rawBuffer, 0, [1 - self.rawBuffer[0]])
+                self.rawBuffer = np.append(self.rawBuffer, [1 - self.rawBuffer[-1]])
+                self.chunk_id += 1
+
+                edges = np.insert(np.diff(self.rawBuffer), 0, [0])
+                edge_positions = np.ravel(np.nonzero(edges))
+
+                if edge_positions.size > 0:
+                    symbols = np.diff(edge_positions) * 1e6 / self.sample_rate
+                    pieces, symbols_size, symbols_shape0 = self._split_like_numpy1(symbols, self.reset_limit)
+
+                    if symbols_shape0 > 1:
+                        self.state = "frame"
+
+                    for symbol_chunk in pieces:
+                        if (symbols_size == 1) or self.state == "idle":
+                            symbol_chunk = symbol_chunk[1::]
+                        if symbol_chunk.size > 0:
+                            self.state = "frame"
+                            if (self.currentSymbols.size > 0) and (self.previousSymbolType == self.currentSymbolType):
+                                self.currentSymbols[-1] += symbol_chunk[0]
+                                symbol_chunk = symbol_chunk[1::]
+
+                            self.currentSymbols = np.append(self.currentSymbols, symbol_chunk)
+
+                            if self.currentSymbols[0] > self.reset_limit:
+                                self.currentSymbols = self.currentSymbols[1::]
+
+                            if (self.currentSymbols.size > 1) and (self.currentSymbols[-1] > self.reset_limit):
+                                self._decode_packet()
+                                self.currentSymbols = np.empty(0, dtype=np.uint8)
+                            else:
+                                self.debug("Waiting for more data", TRACE)
+                        else:
+                            self.debug("skipping empty chunk", INFO)
+                            self.state = "idle"
+                else:
+                    self.debug("no edges in chunk", INFO)
+                self.previousSymbolType = self.rawBuffer[-2]
+            else:
+                self.state = "idle"
+            self.rawBuffer = np.empty(0, dtype=np.uint8)
+        else:
+            self.debug("filling rawBuffer", TRACE)
+
+
+class TS33CStreamDecoder(_StreamFrontEnd):
+    """TS33C/stream_decoder.py:13-220 (GRC twin TS33C/live_decoder.grc:630-845)."""
+
+    def __init__(self, sample_rate=20000, debug_level=0):
+        _StreamFrontEnd.__init__(self, sample_rate, debug_level)
+        self.pulse_short_limit = 775
+        self.gap_short_limit = 775
+        self.reset_limit = 2 * self.gap_short_limit
+        self.temperature = 0
+        self.humidity = 0
+
+    def _decode_packet(self):
+        # TS33C/stream_decoder.py:112-202
+        pulses = self.currentSymbols[0::2]
+        gaps = self.currentSymbols[1::2]
+        gaps = np.where(gaps > self.reset_limit, 0, gaps)
+        pulse_histogram = np.histogram(pulses, "auto")
+        gap_histogram = np.histogram(gaps[np.where(gaps > 0)], "auto")
+        self.pulse_short_limit = pulse_histogram[1][pulse_histogram[1].size // 2]
+        self.gap_short_limit = gap_histogram[1][gap_histogram[1].size // 2]
+
+        combined = np.empty(pulses.size + gaps.size, dtype=pulses.dtype)
+        combined[0::2] = pulses
+        combined[1::2] = gaps
+
+        rawBits = np.empty(combined.size, dtype=np.uint8)
+        rawBits[0::2] = np.where(combined[0::2] < self.pulse_short_limit, 1, 0)
+        rawBits[1::2] = np.where(combined[1::2] < self.gap_short_limit, 255, 0)
+        rawBits = rawBits[np.where(rawBits <= 1)]
+
+        parityMask = np.mod(np.arange(rawBits.size) + 1, 9) == 0
+        parityBits = np.extract(parityMask, rawBits) == 1
+        packetBits = np.extract(np.invert(parityMask), rawBits) == 1
+
+        frame = {"status": None, "packet": None, "pulse_short_limit": float(self.pulse_short_limit),
+                 "gap_short_limit": float(self.gap_short_limit), "nbits": int(rawBits.size)}
+        if (packetBits.size % 8) == 0:
+            packet = np.packbits(np.invert(packetBits[::-1]))[::-1]
+            frame["packet"] = bytes(bytearray(packet.tolist()))
+            self.debug(("packet:", packet.size, packet), INFO)
+            packetParity = (np.sum(np.split(np.invert(packetBits[::-1]), np.arange(8, packetBits.size, 8)), axis=1)[::-1] % 2) == 0
+            if np.array_equal(packetParity, parityBits):
+                if (packet.size == 10) and (packet[0] == 0x9f):
+                    p = [int(b) for b in packet]
+                    channel = (p[1] >> 5) & 0x0F
+                    if channel >= 5:
+                        channel -= 1
+                    rollingCode = p[1] & 0x0F
+                    temp = (p[5] & 0x0F) * 100 + ((p[4] & 0xF0) >> 4) * 10 + (p[4] & 0x0F)
+                    sign = (((p[5] >> 7) & 0x01) * 2) - 1
+                    self.temperature = temp * sign / 10.
+                    battery_ok = (p[5] >> 6) & 0x01 == 1
+                    self.humidity = ((p[6] & 0xF0) >> 4) * 10 + (p[6] & 0x0F)
+                    self.debug(("Channel:", channel), INFO)
+                    self.debug(("Rolling Code:", rollingCode), INFO)
+                    self.debug(("Battery ok:", battery_ok), INFO)
+                    self._print("Temperature: %02.1f°C" % self.temperature)
+                    self._print("Humidity: %02i%%" % self.humidity)
+                    frame.update(status="ok", channel=channel, rolling_code=rollingCode,
+                                 battery_ok=battery_ok, temperature=self.temperature,
+                                 humidity=self.humidity)
+                else:
+                    self.debug("Unknown Sensor or Header", ERROR)
+                    frame["status"] = "Unknown Sensor or Header"
+            else:
+                self.debug("Parity check failed", ERROR)
+                frame["status"] = "Parity check failed"
+        else:
+            self.debug("Invalid packet length", ERROR)
+            frame["status"] = "Invalid packet length"
+        self.frames.append(frame)
+
+
+def crc8(data):
+    """TFA/stream_decoder.py:44-57: CRC-8 poly 0x31, init 0, MSB first."""
+    generator = 0x31
+    crc = 0
+    for currByte in data:
+        crc ^= int(currByte)
+        for _ in range(8):
+            if (crc & 0x80) != 0:
+                crc = ((crc << 1) ^ generator) & 0xFF
+            else:
+                crc <<= 1
+    return crc
+
+
+class TFAStreamDecoder(_StreamFrontEnd):
+    """TFA/stream_decoder.py:13-218; ``nan_guard=True`` gives the GRC twin
+    TFA/analyzer2.grc:765-983 ("Symbol length error" on an empty sync)."""
+
+    def __init__(self, sample_rate=20000, debug_level=0, nan_guard=False):
+        _StreamFrontEnd.__init__(self, sample_rate, debug_level)
+        self.pulse_short_limit = 30
+        self.gap_short_limit = 30
+        self.reset_limit = 500
+        self.nan_guard = nan_guard
+        self.identifier = 0
+        self.temperature = 0
+        self.humidity = 0
+        self.battery_ok = False
+
+    crc8 = staticmethod(crc8)
+
+    def _decode_packet(self):
+        # TFA/stream_decoder.py:132-199
+        self.currentSymbols = self.currentSymbols[6:]
+        sync = self.currentSymbols[:2 * 75]
+        with np.errstate(all="ignore"):
+            import warnings
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                symbol_length = np.mean(np.sum(np.reshape(sync, (-1, 2)), axis=1))
+        frame = {"status": None, "packet": None, "symbol_length": float(symbol_length)}
+        if self.nan_guard and math.isnan(symbol_length):
+            self.debug("Symbol length error", ERROR)
+            frame["status"] = "Symbol length error"
+            self.frames.append(frame)
+            return
+        baudrate = int(1e6 / symbol_length)  # raises on NaN like the reference
+        del baudrate
+        data_start = np.where(self.currentSymbols > symbol_length * 1.5)[0][0]
+        pulses = self.currentSymbols[data_start:-1:2]
+        pulses = np.where(pulses < symbol_length, 0, pulses)
+        gaps = self.currentSymbols[data_start + 1:-1:2]
+        combined = np.empty(pulses.size + gaps.size, dtype=pulses.dtype)
+        combined[0::2] = np.floor(pulses / symbol_length)
+        combined[1::2] = np.ceil(gaps / symbol_length)
+
+        rawBits = np.empty(0, dtype=np.uint8)
+        for index, symbol in np.ndenumerate(combined):
+            if symbol:
+                if not index[0] % 2:
+                    rawBits = np.append(rawBits, np.ones(int(symbol), dtype=np.uint8))
+                else:
+                    rawBits = np.append(rawBits, np.zeros(int(symbol), dtype=np.uint8))
+        frame["nbits"] = int(rawBits.size)
+        if rawBits.size >= 11 * 8:
+            packet = np.packbits(rawBits[:11 * 8][::-1])[::-1]
+            frame["packet"] = bytes(bytearray(packet.tolist()))
+            p = [int(b) for b in packet]
+            if crc8(p[2:10]) == p[10]:
+                self.debug(("packet:", packet.size, packet), INFO)
+                self.identifier = "{:02X}".format((p[2] << 8) + p[3])
+                self.temperature = (p[4] & 0x0f) * 10 + ((p[5] >> 4) & 0x0f) * 1 + (p[5] & 0x0f) * 0.1 - 40
+                self.humidity = (p[6] & 0x7f)
+                self.battery_ok = (p[7] >> 7) & 0x01 == 0
+                self.debug(("Identifier:", self.identifier), INFO)
+                self.debug(("Battery ok:", self.battery_ok), INFO)
+                self._print("Temperature: %02.1f°C" % self.temperature)
+                self._print("Humidity: %02i%%" % self.humidity)
+                frame.update(status="ok", identifier=self.identifier, temperature=self.temperature,
+                             humidity=self.humidity, battery_ok=self.battery_ok)
+            else:
+                self.debug("CRC-Check failed", ERROR)
+                frame["status"] = "CRC-Check failed"
+        else:
+            self.debug("Invalid packet length", ERROR)
+            frame["status"] = "Invalid packet length"
+        self.frames.append(frame)
+
+
+# --------------------------------------------------------------------- somfy
+SOMFY_COMMANDS = {0x00: 'null', 0x01: 'stop', 0x02: 'up', 0x04: 'down', 0x08: 'prog'}
+
+
+def somfy_decode(manchester):
+    """somfy/decoder.py:27-65 on a 112-element half-symbol array."""
+    manchester = np.asarray(manchester)
+    bits = np.ravel(np.where(np.reshape(manchester, (-1, 2)) == [0, 1], 1, 0))[::2]
+    payload = np.packbits(bits)
+    frame = np.zeros(7, dtype=np.uint8)
+    frame[0] = payload[0]
+    for i in range(1, 7):
+        frame[i] = payload[i] ^ payload[i - 1]
+    cksum = 0
+    for i in range(0, 7):
+        cksum = cksum ^ int(frame[i]) ^ (int(frame[i]) >> 4)
+    cksum = cksum & 0xf
+    rolling_code = unpack(">H", frame[2:4].tobytes())[0]
+    address = unpack("<I", frame[4:7].tobytes() + b"\x00")[0]
+    control = (int(frame[1]) >> 4) & 0x0f
+    return {"payload": bytes(bytearray(payload.tolist())), "frame": bytes(bytearray(frame.tolist())),
+            "checksum_ok": cksum == 0, "key": int(frame[0]), "control": control,
+            "rolling_code": rolling_code, "address": address}
+
+
+class SomfySniffer(object):
+    """somfy/sniff.py:19-119 callback rule on (level, tick) edge events.
+    level 1 = end of gap, 0 = end of pulse, 2 = watchdog (20 ms, :167)."""
+
+    def __init__(self):
+        self.start_tick = 0
+        self.state = 0
+        self.bits = np.empty(0, dtype=np.uint8)
+        self.hw_sync = np.empty(0)
+        self.tolerance = 100
+        self.clock = 640
+        self.frames = []
+
+    def cbf(self, level, tick):
+        tol = self.tolerance
+        if level == 1:
+            delta = (tick - self.start_tick) & 0xFFFFFFFF
+            self.start_tick = tick
+            if (0 <= self.state <= 2) and (delta in range(2500 - 2 * tol, 2500 + 2 * tol)):
+                if self.state < 2:
+                    self.hw_sync = np.empty(0)
+                self.hw_sync = np.append(self.hw_sync, [delta])
+                self.state = 2
+            elif (self.state == 3) and (delta in range(2 * self.clock - tol, 2 * self.clock + tol)):
+                self.bits = np.append(self.bits, [0, 0])
+            elif (self.state == 3) and (delta in range(self.clock - tol, self.clock + tol)):
+                self.bits = np.append(self.bits, [0])
+        elif level == 0:
+            delta = (tick - self.start_tick) & 0xFFFFFFFF
+            self.start_tick = tick
+            if (self.state == 0) and (delta in range(10050 - tol, 10050 + tol)):
+                self.state = 1
+            elif (0 <= self.state <= 2) and (delta in range(2500 - 2 * tol, 2500 + 2 * tol)):
+                if self.state < 2:
+                    self.hw_sync = np.empty(0)
+                self.hw_sync = np.append(self.hw_sync, [delta])
+                self.state = 2
+            elif (self.state == 2) and (delta in range(4850 - 2 * tol, 4850 + 2 * tol)):
+                self.clock = int(np.average(self.hw_sync) / 4)
+                self.bits = np.empty(0, dtype=np.uint8)
+                self.state = 3
+            elif (self.state == 3) and (delta in range(2 * self.clock - tol, 2 * self.clock + tol)):
+                self.bits = np.append(self.bits, [1, 1])
+            elif (self.state == 3) and (delta in range(self.clock - tol, self.clock + tol)):
+                self.bits = np.append(self.bits, [1])
+        elif (level == 2) and (self.state > 0):
+            bits = self.bits[1::]
+            if bits.size < 112:
+                bits = np.append(bits, [0])
+            if bits.size == 112:
+                decoded = np.ravel(np.where(np.reshape(bits, (-1, 2)) == [0, 1], 1, 0))[::2]
+                frame = np.packbits(decoded.astype(np.uint8))
+                raw = bytes(bytearray(frame.tolist()))
+                for i in range(frame.size - 1, 0, -1):
+                    frame[i] = frame[i] ^ frame[i - 1]
+                cksum = int(frame[0]) ^ (int(frame[0]) >> 4)
+                for i in range(1, 7):
+                    cksum = cksum ^ int(frame[i]) ^ (int(frame[i]) >> 4)
+                cksum = cksum & 0x0f
+                self.frames.append({"raw": raw, "frame": bytes(bytearray(frame.tolist())),
+                                    "checksum_ok": cksum == 0, "clock": self.clock,
+                                    "control": (int(frame[1]) >> 4) & 0x0f,
+                                    "rolling_code": (int(frame[2]) << 8) | int(frame[3]),
+                                    "address": int(frame[4]) | (int(frame[5]) << 8) | (int(frame[6]) << 16)})
+            self.bits = np.empty(0, dtype=np.uint8)
+            self.state = 0
+
+
+class SomfyPreambleBlock(object):
+    """somfy/epy_block_1.py:14-67 (work() only; the gr.sync_block plumbing is
+    not part of the arithmetic)."""
+
+    def __init__(self, bit_length=1e-6):
+        self.bit_length = bit_length
+        self.state = 0
+        self.preamble = 0
+        self.position = 0
+        self.prints = []
+
+    def work(self, input_items, output_items):
+        self.position = self.position + len(input_items[0])
+        if self.state == 0:
+            if sum(input_items[0]) > 0:
+                self.preamble = sum(input_items[0])
+                self.prints.append(("position of preamble", self.position - self.preamble))
+                self.state = 1
+                zeros = np.zeros(len(input_items[0]))
+                zeros[np.nonzero(input_items[0])[0][0]] = 1.
+                output_items[0][:] = zeros
+            else:
+                output_items[0][:] = [0]
+        elif self.state == 1:
+            self.prints.append((len(input_items[0]), sum(input_items[0])))
+            if sum(input_items[0]) < len(input_items[0]):
+                self.preamble = self.preamble + sum(input_items[0])
+                self.state = 2
+                self.prints.append(("length of preamble", self.preamble))
+                output_items[0][:] = np.gradient(input_items[0], 0.5)
+            else:
+                self.preamble = self.preamble + sum(input_items[0])
+                output_items[0][:] = [1]
+        else:
+            output_items[0][:] = [1]
+        return len(output_items[0])
+
+
+# -------------------------------------------------------------------- berner
+class BernerSniffer(object):
+    """berner/sniff.py:17-44 callback rule."""
+
+    def __init__(self):
+        self.start_tick = 0
+        self.state = 0
+        self.bits = None
+        self.frames = []
+
+    def cbf(self, level, tick):
+        if level == 1:
+            self.start_tick = tick
+        elif level == 0:
+            delta = (tick - self.start_tick) & 0xFFFFFFFF
+            if (self.state == 0) and (delta > 5300) and (delta < 5700):
+                self.bits = np.empty(0, dtype=np.uint8)
+                self.state = 1
+            elif (self.state == 1) and (delta < 500):
+                self.bits = np.append(self.bits, [0])
+            elif (self.state == 1) and (delta > 500) and (delta < 1000):
+                self.bits = np.append(self.bits, [1])
+            elif self.state == 1:
+                if self.bits.size >= 32:
+                    self.frames.append(bytes(bytearray(np.packbits(self.bits.astype(np.uint8))[:4].tolist())))
+                self.state = 0
+
+
+# --------------------------------------------------------------------- mumbi
+class MumbiSniffer(object):
+    """mumbi/sniff.py:19-65 callback rule (watchdog 8 ms, :112)."""
+
+    def __init__(self):
+        self.start_tick = 0
+        self.state = 0
+        self.bits = np.empty(0, dtype=np.uint8)
+        self.tolerance = 50
+        self.frames = []
+
+    def cbf(self, level, tick):
+        tol = self.tolerance
+        if level == 1:
+            self.start_tick = tick
+        elif level == 0:
+            delta = (tick - self.start_tick) & 0xFFFFFFFF
+            if delta in range(820 - 2 * tol, 820 + 2 * tol):
+                self.bits = np.append(self.bits, [1])
+                self.state = 1
+            elif delta in range(300 - tol, 300 + tol):
+                self.bits = np.append(self.bits, [0])
+        elif (level == 2) and (self.state > 0):
+            if self.bits.size == 34:
+                self.frames.append(bytes(bytearray(np.packbits(self.bits.astype(np.uint8)).tolist())))
+            self.bits = np.empty(0, dtype=np.uint8)
+            self.state = 0
+
+
+def edges_to_events(bits, sample_rate, watchdog_us=None, start_level=0):
+    """Turn a sliced 0/1 stream into the (level, tick) events a pigpio
+    EITHER_EDGE callback with an optional watchdog would deliver: tick = sample
+    index of the first sample at the new level, in integer microseconds
+    (floor); one watchdog event (level 2) per run longer than ``watchdog_us``,
+    at run start + watchdog_us.  This is the harness that feeds the *Sniffer
+    rules from IQ-derived bits (the reference fed them from a GPIO pin)."""
+    b = np.asarray(bits).astype(np.int8)
+    ev = []
+    if b.size == 0:
+        return ev
+    pos = np.flatnonzero(np.diff(b)) + 1
+    level = int(start_level)
+    prev_tick = 0
+    starts = np.concatenate(([0], pos))
+    levels = b[starts]
+    if levels[0] != level:
+        ev.append((int(levels[0]), 0))
+    level = int(levels[0])
+    for k in range(1, starts.size):
+        tick = int(starts[k] * 1000000 // sample_rate)
+        if watchdog_us is not None and tick - prev_tick > watchdog_us:
+            ev.append((2, prev_tick + watchdog_us))
+        ev.append((int(levels[k]), tick))
+        prev_tick = tick
+    end_tick = int(b.size * 1000000 // sample_rate)
+    if watchdog_us is not None and end_tick - prev_tick > watchdog_us:
+        ev.append((2, prev_tick + watchdog_us))
+    return ev

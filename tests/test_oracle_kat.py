@@ -1,0 +1,173 @@
+"""Pins oracle/decoders.py to every known-answer vector the reference holds
+for the decoder path.  CPU only."""
+import numpy as np
+import pytest
+
+from oracle import decoders as dec
+from sdr_amd import synth
+
+
+def _bits_from_runs(pulses, gaps, lead=600):
+    out = [np.zeros(lead, np.int8)]
+    for p, g in zip(pulses, gaps):
+        out.append(np.ones(p, np.int8))
+        out.append(np.zeros(g, np.int8))
+    return np.concatenate(out)
+
+
+def test_ts33c_readme_packet(kat):
+    k = kat["ts33c_readme"]
+    bits = _bits_from_runs(k["pulses"], k["gaps"])
+    d = dec.TS33CStreamDecoder(sample_rate=k["sample_rate_hz"])
+    d.work([bits])
+    assert len(d.frames) == 1
+    f = d.frames[0]
+    assert f["status"] == "ok"
+    assert f["nbits"] == k["nbits"]
+    assert f["packet"].hex() == k["packet_hex"]
+    assert f["channel"] == k["channel"] and f["rolling_code"] == k["rolling_code"]
+    assert f["battery_ok"] == k["battery_ok"]
+    assert d.temperature == pytest.approx(k["temperature"]) and d.humidity == k["humidity"]
+    assert d.prints == ["Temperature: 21.6°C", "Humidity: 39%"]
+    # histogram limits 680 / 798 us under numpy 2.2.6
+    assert f["pulse_short_limit"] == pytest.approx(680.0)
+    assert f["gap_short_limit"] == pytest.approx(798.0)
+
+
+def test_ts33c_readme_bitbuffer(kat):
+    """rtl_433's 90-bit buffer == the raw bits the rule yields."""
+    k = kat["ts33c_readme"]
+    want = np.unpackbits(np.frombuffer(bytes.fromhex(k["bitbuffer_hex"]), np.uint8))[:90]
+    raw = []
+    for p, g in zip(k["pulses"], k["gaps"]):
+        raw.append(1 if p * 4 < 680 else 0)
+        if g * 4 >= 798 and g * 4 <= 1550:
+            raw.append(0)
+    assert raw == want.tolist()
+
+
+@pytest.mark.parametrize("nchunks", [1, 3, 100, 200])
+def test_ts33c_readme_chunked(kat, nchunks):
+    """main() of the reference streams array_split chunks (stream_decoder.py:230-235)."""
+    k = kat["ts33c_readme"]
+    bits = _bits_from_runs(k["pulses"], k["gaps"])
+    bits = np.concatenate([bits, bits, np.zeros(3000, np.int8)])
+    d = dec.TS33CStreamDecoder(sample_rate=k["sample_rate_hz"])
+    for c in np.array_split(bits, nchunks):
+        d.work([c])
+    ok = [f for f in d.frames if f["status"] == "ok"]
+    assert len(ok) == 2 and all(f["packet"].hex() == k["packet_hex"] for f in ok)
+
+
+def test_ts33c_png2_bits(kat):
+    """docs/Decoding Description 2.png: 90 raw bits -> packet -> +8.2 C / 53 %."""
+    k = kat["ts33c_png2"]
+    raw = [int(c) for g in k["raw_groups"] for c in g]
+    assert len(raw) == 90
+    sym = synth.ts33c_symbols(raw)
+    env = synth.envelope(sym, 20000.0, lead_in_us=5000.0)
+    d = dec.TS33CStreamDecoder(sample_rate=20000)
+    d.work([env.astype(np.int8)])
+    assert [f["status"] for f in d.frames] == ["ok"]
+    assert d.frames[0]["packet"].hex() == k["packet_hex"]
+    assert d.temperature == pytest.approx(k["temperature"]) and d.humidity == k["humidity"]
+
+
+def test_synth_ts33c_inverse(kat):
+    """synth.ts33c_bits/ts33c_packet are the inverse of the reference decode."""
+    k = kat["ts33c_readme"]
+    pkt = synth.ts33c_packet(channel=1, rolling_code=1, temp_tenths=216, humidity=39, battery_ok=True)
+    assert pkt.hex() == k["packet_hex"]
+    want = np.unpackbits(np.frombuffer(bytes.fromhex(k["bitbuffer_hex"]), np.uint8))[:90].tolist()
+    assert synth.ts33c_bits(pkt) == want
+    # the greedy pulse/gap encoder reproduces the README's long/short pattern
+    sym = synth.ts33c_symbols(want)
+    assert len(sym) == 2 * len(k["pulses"])
+    for (lvl, dur), ref in zip(sym[:-1], [v for pg in zip(k["pulses"], k["gaps"]) for v in pg]):
+        assert (dur > 700) == (ref * 4 > 700)
+
+
+def test_tfa_crc_and_fields(kat):
+    for name in ("tfa_readme", "tfa_png"):
+        k = kat[name]
+        p = list(bytes.fromhex(k["packet_hex"]))
+        assert dec.crc8(p[2:10]) == p[10]
+
+
+def test_tfa_png_bits_to_packet(kat):
+    k = kat["tfa_png"]
+    raw = np.array([int(c) for c in k["raw_bits"]], np.uint8)
+    packet = np.packbits(raw[:88][::-1])[::-1]
+    assert bytes(packet.tolist()).hex() == k["packet_hex"]
+
+
+@pytest.mark.parametrize("name", ["tfa_readme", "tfa_png"])
+@pytest.mark.parametrize("nchunks", [1, 200])
+def test_tfa_stream_decoder(kat, name, nchunks):
+    k = kat[name]
+    pkt = bytes.fromhex(k["packet_hex"])
+    sym = synth.tfa_symbols(synth.tfa_bits(pkt))
+    env = synth.envelope(sym, 2e6, lead_in_us=900.0)
+    env = np.concatenate([env, np.zeros(2000, np.uint8)]).astype(np.int8)
+    d = dec.TFAStreamDecoder(sample_rate=2000000)
+    for c in np.array_split(env, nchunks):
+        d.work([c])
+    assert [f["status"] for f in d.frames] == ["ok"]
+    assert d.frames[0]["packet"].hex() == k["packet_hex"]
+    assert d.identifier == k["identifier"]
+    assert d.temperature == pytest.approx(k["temperature"])
+    assert d.humidity == k["humidity"] and d.battery_ok == k["battery_ok"]
+
+
+def test_somfy_kat(kat):
+    k = kat["somfy_stop"]
+    r = dec.somfy_decode(k["manchester"])
+    assert r["payload"].hex() == k["payload_hex"]
+    assert r["frame"].hex() == k["frame_hex"]
+    assert r["checksum_ok"] is True
+    assert (r["control"], r["rolling_code"], r["address"], r["key"]) == (
+        k["control"], k["rolling_code"], k["address"], k["key"])
+    # transmitter side: synth.somfy_frame reproduces the on-air bytes
+    assert synth.somfy_frame(0xA0, 0x01, 5, 0x365240).hex() == k["payload_hex"]
+    k2 = kat["somfy_readme2"]
+    f = list(bytes.fromhex(k2["frame_hex"]))
+    for i in range(1, 7):
+        f[i] ^= f[i - 1]
+    assert bytes(f).hex() == k2["payload_hex"]
+    ck = 0
+    for b in bytes.fromhex(kat["somfy_readme_cksum"]["frame_hex"]):
+        ck ^= b ^ (b >> 4)
+    assert (ck & 0xf) == 0
+
+
+def test_somfy_sniffer_on_synth(kat):
+    k = kat["somfy_stop"]
+    sym = synth.somfy_symbols(bytes.fromhex(k["payload_hex"]), repeats=1)
+    env = synth.envelope(sym, 1e6, lead_in_us=3000.0)
+    s = dec.SomfySniffer()
+    for lvl, tick in dec.edges_to_events(env, 1e6, watchdog_us=20000):
+        s.cbf(lvl, tick)
+    assert len(s.frames) == 2
+    for f in s.frames:
+        assert f["raw"].hex() == k["payload_hex"] and f["frame"].hex() == k["frame_hex"]
+        assert f["checksum_ok"] and f["rolling_code"] == 5 and f["address"] == 0x365240
+
+
+def test_mumbi_sniffer(kat):
+    for name, code in kat["mumbi_codes"].items():
+        env = synth.envelope(synth.mumbi_symbols(bytes(code), repeats=3), 1e6, lead_in_us=9000.0)
+        s = dec.MumbiSniffer()
+        for lvl, tick in dec.edges_to_events(env, 1e6, watchdog_us=8000):
+            s.cbf(lvl, tick)
+        want = np.packbits(np.unpackbits(np.array(code, np.uint8))[:34])
+        assert s.frames == [bytes(want.tolist())] * 3, name
+
+
+def test_berner_sniffer(kat):
+    code = int(kat["berner_example"]["code_hex"], 16)
+    env = synth.envelope(synth.berner_symbols(code, repeats=5), 1e6, lead_in_us=3000.0)
+    s = dec.BernerSniffer()
+    for lvl, tick in dec.edges_to_events(env, 1e6):
+        s.cbf(lvl, tick)
+    # every other frame: the next preamble pulse is consumed as the end marker
+    assert s.frames == [bytes.fromhex(kat["berner_example"]["code_hex"])] * 3
