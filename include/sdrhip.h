@@ -1,0 +1,195 @@
+/*
+ * sdrhip.h -- C ABI of libsdrhip.so: the MI355X (gfx950) receive chain that
+ * stands in for the GNU Radio blocks + embedded Python decoders of
+ * henrythasler/sdr.  POD structs, plain pointers and sizes only; no C++ or
+ * torch types cross this boundary.  Every entry point returns 0 on success or
+ * a negative SDR_E_* code and never throws; sdr_last_error() gives the text.
+ *
+ * One handle = one configured chain (what one GRC flowgraph wires up) with its
+ * own HIP stream and device buffers.  Calls on one handle are serialised by
+ * the caller; different handles may be used from different threads
+ * (GNU Radio runs one thread per block and calls work() serially per block).
+ *
+ * "ref:" comments name the reference interface each entry point replaces
+ * (paths relative to the reference checkout).
+ */
+#ifndef SDRHIP_H
+#define SDRHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SDR_API __attribute__((visibility("default")))
+
+/* error codes */
+enum {
+    SDR_OK = 0,
+    SDR_E_ARG = -1,      /* bad argument / configuration */
+    SDR_E_HIP = -2,      /* HIP runtime error (text in sdr_last_error) */
+    SDR_E_CAPACITY = -3, /* input larger than the handle was created for */
+    SDR_E_OVERFLOW = -4, /* device-side table (runs / frames) overflowed */
+    SDR_E_NODEVICE = -5  /* no usable gfx950 device */
+};
+
+/* gr::filter::firdes::win_type values, as the GRC files store them
+ * (ref: TS33C/live_decoder.grc:917-988 `win firdes.WIN_HAMMING`). */
+enum { SDR_WIN_HAMMING = 0, SDR_WIN_HANN = 1, SDR_WIN_BLACKMAN = 2, SDR_WIN_RECTANGULAR = 3,
+       SDR_WIN_KAISER = 4, SDR_WIN_BLACKMAN_HARRIS = 5 };
+
+/* demodulator after the channel filter */
+enum {
+    SDR_DEMOD_NONE = 0, /* complex out (filter stage only) */
+    SDR_DEMOD_MAG2 = 1, /* blocks_complex_to_mag_squared (ref: TS33C/live_decoder.grc:307-349) */
+    SDR_DEMOD_QUAD = 2  /* analog_quadrature_demod_cf (ref: TFA/decoder.grc:450-481) */
+};
+
+/* bit decoder fed by the sliced stream */
+enum {
+    SDR_DEC_NONE = 0,
+    SDR_DEC_TS33C = 1,  /* ref: TS33C/stream_decoder.py:13-220 */
+    SDR_DEC_TFA = 2,    /* ref: TFA/stream_decoder.py:13-218 */
+    SDR_DEC_TFA_GRC = 3,/* ref: TFA/analyzer2.grc:765-983 (adds the NaN guard) */
+    SDR_DEC_SOMFY = 4,  /* ref: somfy/sniff.py:28-117 + somfy/decoder.py:27-58 */
+    SDR_DEC_BERNER = 5, /* ref: berner/sniff.py:21-44 */
+    SDR_DEC_MUMBI = 6   /* ref: mumbi/sniff.py:26-65 */
+};
+
+/* frame status (the reference reports these as debug strings) */
+enum {
+    SDR_FRAME_OK = 0,
+    SDR_FRAME_BAD_LENGTH = 1,     /* "Invalid packet length" */
+    SDR_FRAME_PARITY = 2,         /* "Parity check failed" */
+    SDR_FRAME_UNKNOWN_HEADER = 3, /* "Unknown Sensor or Header" */
+    SDR_FRAME_CRC = 4,            /* "CRC-Check failed" */
+    SDR_FRAME_SYMBOL_LENGTH = 5,  /* "Symbol length error" (GRC twin only) */
+    SDR_FRAME_CHECKSUM = 6,       /* somfy checksum != 0 */
+    SDR_FRAME_EXC_RESHAPE = 16,   /* reference raises ValueError (odd sync count, TFA/stream_decoder.py:137) */
+    SDR_FRAME_EXC_INDEX = 17,     /* reference raises IndexError (no data start, TFA/stream_decoder.py:143) */
+    SDR_FRAME_EXC_NAN = 18        /* reference raises ValueError int(NaN) (TFA/stream_decoder.py:138) */
+};
+
+/* One flowgraph's parameters.  Field names follow the GRC block parameters.
+ * ref: the <block> parameter lists of TS33C/live_decoder.grc:3292-3377 wiring. */
+typedef struct sdr_chain_cfg {
+    double sample_rate;  /* samp_rate of the IQ stream, Hz */
+    double center_freq;  /* freq_xlating_fir_filter center_freq, Hz; 0 = plain fir_filter_ccf */
+    int32_t decim;       /* channel-filter decimation D (>=1) */
+    int32_t demod;       /* SDR_DEMOD_* */
+    float demod_gain;    /* multiply_const after mag2, or quadrature_demod gain */
+    float thr_lo;        /* threshold_ff low */
+    float thr_hi;        /* threshold_ff high */
+    int32_t thr_init;    /* threshold_ff initial state */
+    int32_t keep_n;      /* keep_one_in_n after the slicer (>=1) */
+    int32_t decoder;     /* SDR_DEC_* */
+    double decoder_rate; /* sample_rate parameter of the decoder block; 0 = sample_rate/decim/keep_n */
+    int32_t post_ntaps;  /* >0: real low_pass_filter on the demodulated floats (TFA/analyzer2.grc:1075-1147); taps via sdr_set_post_taps */
+    int32_t tap_demod;   /* !=0: keep the demodulated floats for sdr_fetch_demod (parity tests) */
+    int32_t max_batch;   /* captures per sdr_batch_process call (>=1) */
+    int32_t max_frames;  /* frame records kept per capture / per stream call */
+    uint64_t max_samples;/* IQ samples per capture / per streaming call */
+} sdr_chain_cfg;
+
+/* A decoded frame, fixed size.  Integers only; the Python mirror formats the
+ * reference's print lines from them. */
+typedef struct sdr_frame {
+    int32_t capture;   /* capture index inside the batch (0 when streaming) */
+    int32_t decoder;   /* SDR_DEC_* */
+    int32_t status;    /* SDR_FRAME_* */
+    int32_t nbits;     /* raw bits the symbol rule produced */
+    int32_t nbytes;    /* valid bytes in `bytes` */
+    uint8_t bytes[16]; /* packet (TS33C 10, TFA 11, somfy 7 de-obfuscated, berner 4, mumbi 5) */
+    uint8_t raw[8];    /* somfy: the 7 on-air (obfuscated) bytes */
+    int32_t v[4];      /* TS33C: channel, rolling code, battery_ok, humidity | TFA: id, humidity, battery_ok, 0 | somfy: control, rolling code, address, clock */
+    int32_t temp_tenths; /* TS33C/TFA temperature in 0.1 C */
+    int32_t pad_;
+    double lim[2];     /* TS33C: pulse/gap short limit (us) | TFA: symbol_length (us), 0 */
+    int64_t end_pos;   /* index (decoder-rate samples, per call) where the frame ended */
+} sdr_frame;
+
+/* per-call summary filled by sdr_process_iq / sdr_batch_process */
+typedef struct sdr_out {
+    uint64_t n_in;     /* IQ samples consumed */
+    uint64_t n_bits;   /* sliced bytes produced (per capture in batch mode) */
+    uint64_t n_frames; /* frame records available to sdr_fetch_frames */
+    int32_t overflow;  /* !=0: a device table overflowed (also returns SDR_E_OVERFLOW) */
+    int32_t pad_;
+} sdr_out;
+
+typedef struct sdr_handle sdr_handle;
+
+/* ---- filter design (host) ------------------------------------------------
+ * ref: the `low_pass_filter` GRC block = firdes.low_pass(gain, samp_rate,
+ * cutoff_freq, width, win, beta), e.g. TS33C/live_decoder.grc:917-988.
+ * Returns ntaps (>0), or -(needed) if cap is too small. */
+SDR_API int sdr_firdes_low_pass(double gain, double fs, double fc, double tw, int win, double beta,
+                                float* taps, int cap);
+/* ref: rational_resampler_xxx with empty taps (FM-Radio/FM-Radio.grc:1378-1493). */
+SDR_API int sdr_resampler_taps(int interp, int decim, double fractional_bw, float* taps, int cap);
+
+/* ---- chain life cycle -----------------------------------------------------
+ * ref: what `top_block.__init__` does when GRC instantiates the blocks. */
+SDR_API int sdr_create(const sdr_chain_cfg* cfg, sdr_handle** out);
+SDR_API int sdr_destroy(sdr_handle* h);
+/* channel-filter taps; n real floats, or n (re,im) pairs when is_complex.
+ * Default after sdr_create is the single tap 1 (ref: `taps 1` in
+ * FM-Radio/FM-Radio.grc:615-671).  With center_freq != 0 the taps are
+ * translated as freq_xlating_fir_filter_ccc does. */
+SDR_API int sdr_set_taps(sdr_handle* h, const float* taps, int n, int is_complex);
+SDR_API int sdr_set_post_taps(sdr_handle* h, const float* taps, int n);
+/* run on a caller-owned HIP stream (hipStream_t as void*), e.g. torch's
+ * current stream; NULL = the handle's own stream. */
+SDR_API int sdr_set_stream(sdr_handle* h, void* hip_stream);
+SDR_API int sdr_synchronize(sdr_handle* h);
+SDR_API const char* sdr_last_error(sdr_handle* h);
+
+/* ---- streaming entry points (state carried in the handle) -----------------
+ * ref: gr::block::general_work of the C++ blocks + blk.work(input_items,
+ * output_items) of the epy decoder (TS33C/live_decoder.grc:665-845): FIR
+ * history, NCO phase, hysteresis bit, keep_one_in_n counter and the decoder's
+ * rawBuffer/currentSymbols state all persist between calls.
+ * iq: n complex64 samples (interleaved re,im), host or device pointer. */
+SDR_API int sdr_process_iq(sdr_handle* h, const void* iq, size_t n, int is_device_ptr, sdr_out* out);
+/* ref: StreamDecoder.work([chunk]) (TS33C/stream_decoder.py:39): decoder only,
+ * bits = n int8 values 0/1 at the decoder rate. */
+SDR_API int sdr_process_bits(sdr_handle* h, const int8_t* bits, size_t n, int is_device_ptr, sdr_out* out);
+
+/* ---- batch entry point -----------------------------------------------------
+ * n_captures independent captures of n_per_capture samples each (capture i at
+ * iq + i*stride samples), every one processed from stream start by a fresh
+ * chain and decoded as ONE work() call on a fresh decoder.
+ * ref: BASELINE.json configs[3]; per capture == TS33C/stream_decoder.py main()
+ * with a single chunk. */
+SDR_API int sdr_batch_process(sdr_handle* h, const void* iq, size_t n_per_capture, size_t stride,
+                              int n_captures, int is_device_ptr, sdr_out* out);
+
+/* ---- results ---------------------------------------------------------------
+ * All fetches synchronise the handle's stream first. */
+SDR_API int sdr_fetch_frames(sdr_handle* h, sdr_frame* out, size_t cap, size_t* n);
+/* sliced byte stream of the last call; capture c of a batch starts at
+ * out + c*n_bits. */
+SDR_API int sdr_fetch_bits(sdr_handle* h, int8_t* out, size_t cap, size_t* n);
+/* demodulated floats of the last call (needs cfg.tap_demod); per capture
+ * n_in/decim values (complex pairs when demod == SDR_DEMOD_NONE). */
+SDR_API int sdr_fetch_demod(sdr_handle* h, float* out, size_t cap, size_t* n);
+/* decoder state, for the Python mirror's attributes
+ * (ref: TS33C/stream_decoder.py:20-32): state[0]=idle(0)/frame(1),
+ * state[1]=pending symbol count, state[2]=previousSymbolType, state[3]=chunk_id. */
+SDR_API int sdr_decoder_state(sdr_handle* h, int32_t state[4]);
+
+/* ---- timing helper ----------------------------------------------------------
+ * HIP events on the stream the kernels run on: sdr_timer_start/stop bracket a
+ * region, sdr_timer_elapsed_ms synchronises on the stop event. */
+SDR_API int sdr_timer_start(sdr_handle* h);
+SDR_API int sdr_timer_stop(sdr_handle* h);
+SDR_API int sdr_timer_elapsed_ms(sdr_handle* h, float* ms);
+
+SDR_API int sdr_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SDRHIP_H */

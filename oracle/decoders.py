@@ -487,12 +487,12 @@ def edges_to_events(bits, sample_rate, watchdog_us=None, start_level=0):
         ev.append((int(levels[0]), 0))
     level = int(levels[0])
     for k in range(1, starts.size):
-        tick = int(starts[k] * 1000000 // sample_rate)
+        tick = int(starts[k]) * 1000000 // int(sample_rate)
         if watchdog_us is not None and tick - prev_tick > watchdog_us:
             ev.append((2, prev_tick + watchdog_us))
         ev.append((int(levels[k]), tick))
         prev_tick = tick
-    end_tick = int(b.size * 1000000 // sample_rate)
+    end_tick = int(b.size) * 1000000 // int(sample_rate)
     if watchdog_us is not None and end_tick - prev_tick > watchdog_us:
         ev.append((2, prev_tick + watchdog_us))
     return ev

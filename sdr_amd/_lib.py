@@ -1,0 +1,178 @@
+"""ctypes binding of libsdrhip.so (include/sdrhip.h).  Thin: struct mirrors,
+argtypes, error mapping.  The library is built in-tree by
+``__graft_entry__.build()`` / ``make -C sdr_amd/csrc``; there is no fallback
+if it is missing."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsdrhip.so")
+
+SDR_OK, SDR_E_ARG, SDR_E_HIP, SDR_E_CAPACITY, SDR_E_OVERFLOW, SDR_E_NODEVICE = 0, -1, -2, -3, -4, -5
+
+WIN_HAMMING, WIN_HANN, WIN_BLACKMAN, WIN_RECTANGULAR, WIN_KAISER, WIN_BLACKMAN_HARRIS = range(6)
+DEMOD_NONE, DEMOD_MAG2, DEMOD_QUAD = 0, 1, 2
+DEC_NONE, DEC_TS33C, DEC_TFA, DEC_TFA_GRC, DEC_SOMFY, DEC_BERNER, DEC_MUMBI = range(7)
+
+FRAME_OK = 0
+FRAME_BAD_LENGTH = 1
+FRAME_PARITY = 2
+FRAME_UNKNOWN_HEADER = 3
+FRAME_CRC = 4
+FRAME_SYMBOL_LENGTH = 5
+FRAME_CHECKSUM = 6
+FRAME_EXC_RESHAPE = 16
+FRAME_EXC_INDEX = 17
+FRAME_EXC_NAN = 18
+
+#: the reference's debug strings for each status (TS33C/stream_decoder.py:198-202,
+#: TFA/stream_decoder.py:197-199, TFA/analyzer2.grc:960)
+STATUS_TEXT = {
+    FRAME_OK: "ok",
+    FRAME_BAD_LENGTH: "Invalid packet length",
+    FRAME_PARITY: "Parity check failed",
+    FRAME_UNKNOWN_HEADER: "Unknown Sensor or Header",
+    FRAME_CRC: "CRC-Check failed",
+    FRAME_SYMBOL_LENGTH: "Symbol length error",
+    FRAME_CHECKSUM: "checksum error",
+}
+
+
+class SdrError(RuntimeError):
+    def __init__(self, code, text):
+        RuntimeError.__init__(self, "libsdrhip error %d: %s" % (code, text))
+        self.code = code
+
+
+class ChainCfg(C.Structure):
+    _fields_ = [
+        ("sample_rate", C.c_double),
+        ("center_freq", C.c_double),
+        ("decim", C.c_int32),
+        ("demod", C.c_int32),
+        ("demod_gain", C.c_float),
+        ("thr_lo", C.c_float),
+        ("thr_hi", C.c_float),
+        ("thr_init", C.c_int32),
+        ("keep_n", C.c_int32),
+        ("decoder", C.c_int32),
+        ("decoder_rate", C.c_double),
+        ("post_ntaps", C.c_int32),
+        ("tap_demod", C.c_int32),
+        ("max_batch", C.c_int32),
+        ("max_frames", C.c_int32),
+        ("max_samples", C.c_uint64),
+    ]
+
+
+class Frame(C.Structure):
+    _fields_ = [
+        ("capture", C.c_int32),
+        ("decoder", C.c_int32),
+        ("status", C.c_int32),
+        ("nbits", C.c_int32),
+        ("nbytes", C.c_int32),
+        ("bytes", C.c_uint8 * 16),
+        ("raw", C.c_uint8 * 8),
+        ("v", C.c_int32 * 4),
+        ("temp_tenths", C.c_int32),
+        ("pad_", C.c_int32),
+        ("lim", C.c_double * 2),
+        ("end_pos", C.c_int64),
+    ]
+
+    def packet(self):
+        return bytes(bytearray(self.bytes[: self.nbytes]))
+
+
+class Out(C.Structure):
+    _fields_ = [
+        ("n_in", C.c_uint64),
+        ("n_bits", C.c_uint64),
+        ("n_frames", C.c_uint64),
+        ("overflow", C.c_int32),
+        ("pad_", C.c_int32),
+    ]
+
+
+#: every symbol include/sdrhip.h declares (checked by tests/test_abi.py)
+EXPORTS = [
+    "sdr_firdes_low_pass", "sdr_resampler_taps", "sdr_create", "sdr_destroy", "sdr_set_taps",
+    "sdr_set_post_taps", "sdr_set_stream", "sdr_synchronize", "sdr_last_error", "sdr_process_iq",
+    "sdr_process_bits", "sdr_batch_process", "sdr_fetch_frames", "sdr_fetch_bits", "sdr_fetch_demod",
+    "sdr_decoder_state", "sdr_timer_start", "sdr_timer_stop", "sdr_timer_elapsed_ms", "sdr_version",
+]
+
+_lib = None
+
+
+def load():
+    """Load libsdrhip.so; raises if it has not been built (no CPU fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("%s not found: build it with __graft_entry__.build() "
+                          "(hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    H = C.c_void_p
+    fp = C.POINTER(C.c_float)
+    L.sdr_firdes_low_pass.restype = C.c_int
+    L.sdr_firdes_low_pass.argtypes = [C.c_double] * 4 + [C.c_int, C.c_double, fp, C.c_int]
+    L.sdr_resampler_taps.restype = C.c_int
+    L.sdr_resampler_taps.argtypes = [C.c_int, C.c_int, C.c_double, fp, C.c_int]
+    L.sdr_create.restype = C.c_int
+    L.sdr_create.argtypes = [C.POINTER(ChainCfg), C.POINTER(H)]
+    L.sdr_destroy.restype = C.c_int
+    L.sdr_destroy.argtypes = [H]
+    L.sdr_set_taps.restype = C.c_int
+    L.sdr_set_taps.argtypes = [H, fp, C.c_int, C.c_int]
+    L.sdr_set_post_taps.restype = C.c_int
+    L.sdr_set_post_taps.argtypes = [H, fp, C.c_int]
+    L.sdr_set_stream.restype = C.c_int
+    L.sdr_set_stream.argtypes = [H, C.c_void_p]
+    L.sdr_synchronize.restype = C.c_int
+    L.sdr_synchronize.argtypes = [H]
+    L.sdr_last_error.restype = C.c_char_p
+    L.sdr_last_error.argtypes = [H]
+    L.sdr_process_iq.restype = C.c_int
+    L.sdr_process_iq.argtypes = [H, C.c_void_p, C.c_size_t, C.c_int, C.POINTER(Out)]
+    L.sdr_process_bits.restype = C.c_int
+    L.sdr_process_bits.argtypes = [H, C.c_void_p, C.c_size_t, C.c_int, C.POINTER(Out)]
+    L.sdr_batch_process.restype = C.c_int
+    L.sdr_batch_process.argtypes = [H, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.POINTER(Out)]
+    L.sdr_fetch_frames.restype = C.c_int
+    L.sdr_fetch_frames.argtypes = [H, C.POINTER(Frame), C.c_size_t, C.POINTER(C.c_size_t)]
+    L.sdr_fetch_bits.restype = C.c_int
+    L.sdr_fetch_bits.argtypes = [H, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.sdr_fetch_demod.restype = C.c_int
+    L.sdr_fetch_demod.argtypes = [H, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.sdr_decoder_state.restype = C.c_int
+    L.sdr_decoder_state.argtypes = [H, C.POINTER(C.c_int32 * 4)]
+    for name in ("sdr_timer_start", "sdr_timer_stop"):
+        getattr(L, name).restype = C.c_int
+        getattr(L, name).argtypes = [H]
+    L.sdr_timer_elapsed_ms.restype = C.c_int
+    L.sdr_timer_elapsed_ms.argtypes = [H, C.POINTER(C.c_float)]
+    L.sdr_version.restype = C.c_int
+    # host-compiled test hooks (csrc/selftest.h); not used by the product path
+    L.sdr_selftest_hist_mid_edge.restype = C.c_int
+    L.sdr_selftest_hist_mid_edge.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double)]
+    L.sdr_selftest_pairwise_mean.restype = C.c_int
+    L.sdr_selftest_pairwise_mean.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double)]
+    L.sdr_selftest_dec_create.restype = C.c_void_p
+    L.sdr_selftest_dec_create.argtypes = [C.c_int, C.c_double]
+    L.sdr_selftest_dec_destroy.restype = None
+    L.sdr_selftest_dec_destroy.argtypes = [C.c_void_p]
+    L.sdr_selftest_dec_work.restype = C.c_int
+    L.sdr_selftest_dec_work.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(Frame), C.c_size_t,
+                                        C.POINTER(C.c_size_t), C.POINTER(C.c_int32 * 4)]
+    _lib = L
+    return L
+
+
+def check(handle, rc):
+    if rc != SDR_OK:
+        L = load()
+        text = L.sdr_last_error(handle)
+        raise SdrError(rc, text.decode("utf-8", "replace") if text else "")

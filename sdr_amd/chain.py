@@ -1,0 +1,187 @@
+"""Receive chain = what one GRC flowgraph wires between the IQ source and the
+decoder block, as one object backed by one libsdrhip handle.
+
+Parameter names follow the GRC blocks: ``low_pass(...)`` is the
+``low_pass_filter`` block's taps (firdes.low_pass), ``Chain(decim=, center_freq=,
+taps=)`` the freq_xlating_fir_filter / fir_filter, ``thr=(low, high)`` the
+threshold block, ``keep_n`` keep_one_in_n (ref: TS33C/live_decoder.grc:3292-3377).
+Inputs may be numpy arrays (copied to the GPU by the library) or torch tensors
+already in HBM (passed by device pointer, no copy)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import (DEC_BERNER, DEC_MUMBI, DEC_NONE, DEC_SOMFY, DEC_TFA, DEC_TFA_GRC, DEC_TS33C,  # noqa: F401
+                   DEMOD_MAG2, DEMOD_NONE, DEMOD_QUAD, WIN_BLACKMAN, WIN_HAMMING, WIN_KAISER)
+
+
+def low_pass(gain, fs, fc, tw, win=WIN_HAMMING, beta=6.76):
+    """firdes.low_pass(gain, sampling_freq, cutoff_freq, transition_width, window, beta)."""
+    L = _lib.load()
+    buf = (C.c_float * 65536)()
+    n = L.sdr_firdes_low_pass(gain, fs, fc, tw, win, beta, buf, 65536)
+    if n <= 0:
+        raise _lib.SdrError(n, "sdr_firdes_low_pass")
+    return np.frombuffer(buf, np.float32, n).copy()
+
+
+def resampler_taps(interp, decim, fractional_bw=0.4):
+    """rational_resampler's design_filter (empty `taps` in GRC)."""
+    L = _lib.load()
+    buf = (C.c_float * 65536)()
+    n = L.sdr_resampler_taps(interp, decim, fractional_bw, buf, 65536)
+    if n <= 0:
+        raise _lib.SdrError(n, "sdr_resampler_taps")
+    return np.frombuffer(buf, np.float32, n).copy()
+
+
+def _is_torch(x):
+    return type(x).__module__.startswith("torch")
+
+
+class Chain(object):
+    def __init__(self, sample_rate, decim=1, center_freq=0.0, taps=None, demod=DEMOD_MAG2, demod_gain=1.0,
+                 thr=(0.05, 0.15), thr_init=0, keep_n=1, decoder=DEC_NONE, decoder_rate=0.0, post_taps=None,
+                 tap_demod=False, max_batch=1, max_frames=16, max_samples=1 << 20):
+        self._L = _lib.load()
+        self._h = C.c_void_p()
+        cfg = _lib.ChainCfg()
+        cfg.sample_rate = float(sample_rate)
+        cfg.center_freq = float(center_freq)
+        cfg.decim = int(decim)
+        cfg.demod = int(demod)
+        cfg.demod_gain = float(demod_gain)
+        cfg.thr_lo, cfg.thr_hi = float(thr[0]), float(thr[1])
+        cfg.thr_init = int(thr_init)
+        cfg.keep_n = int(keep_n)
+        cfg.decoder = int(decoder)
+        cfg.decoder_rate = float(decoder_rate)
+        cfg.post_ntaps = 0 if post_taps is None else int(len(post_taps))
+        cfg.tap_demod = int(bool(tap_demod))
+        cfg.max_batch = int(max_batch)
+        cfg.max_frames = int(max_frames)
+        cfg.max_samples = int(max_samples)
+        self.cfg = cfg
+        rc = self._L.sdr_create(C.byref(cfg), C.byref(self._h))
+        if rc != 0:
+            self._h = C.c_void_p()
+            _lib.check(None, rc)
+        if taps is not None:
+            self.set_taps(taps)
+        if post_taps is not None:
+            pt = np.ascontiguousarray(post_taps, np.float32)
+            _lib.check(self._h, self._L.sdr_set_post_taps(self._h, pt.ctypes.data_as(C.POINTER(C.c_float)), pt.size))
+        self.out = _lib.Out()
+
+    # -- life cycle
+    def close(self):
+        if self._h:
+            self._L.sdr_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def set_taps(self, taps):
+        taps = np.asarray(taps)
+        if np.iscomplexobj(taps):
+            t = np.ascontiguousarray(taps, np.complex64)
+            _lib.check(self._h, self._L.sdr_set_taps(self._h, t.view(np.float32).ctypes.data_as(C.POINTER(C.c_float)), t.size, 1))
+        else:
+            t = np.ascontiguousarray(np.atleast_1d(taps), np.float32)
+            _lib.check(self._h, self._L.sdr_set_taps(self._h, t.ctypes.data_as(C.POINTER(C.c_float)), t.size, 0))
+
+    def set_stream(self, hip_stream_ptr):
+        _lib.check(self._h, self._L.sdr_set_stream(self._h, C.c_void_p(hip_stream_ptr)))
+
+    def synchronize(self):
+        _lib.check(self._h, self._L.sdr_synchronize(self._h))
+
+    # -- data path
+    def _iq_ptr(self, iq):
+        if _is_torch(iq):
+            if not iq.is_cuda:
+                iq = iq.cpu().numpy()
+            else:
+                if not iq.is_contiguous():
+                    raise ValueError("IQ tensor must be contiguous")
+                return iq.data_ptr(), 1, iq
+        a = np.ascontiguousarray(iq, np.complex64)
+        return a.ctypes.data, 0, a
+
+    def process_iq(self, iq):
+        """One streaming call (state carried): n complex64 samples."""
+        ptr, dev, keep = self._iq_ptr(iq)
+        n = int(keep.numel() if dev else keep.size)
+        if dev and not keep.is_complex():
+            n //= 2
+        _lib.check(self._h, self._L.sdr_process_iq(self._h, C.c_void_p(ptr), n, dev, C.byref(self.out)))
+        return self.out
+
+    def process_bits(self, bits):
+        b = np.ascontiguousarray(bits, np.int8)
+        _lib.check(self._h, self._L.sdr_process_bits(self._h, C.c_void_p(b.ctypes.data), b.size, 0, C.byref(self.out)))
+        return self.out
+
+    def batch_process(self, iq):
+        """iq: (n_captures, n_per_capture) complex64 (numpy, or torch on the GPU;
+        a float32 torch tensor of shape (n_captures, n, 2) is accepted too)."""
+        ptr, dev, keep = self._iq_ptr(iq)
+        ncap = int(keep.shape[0])
+        n = int(keep.shape[1])
+        _lib.check(self._h, self._L.sdr_batch_process(self._h, C.c_void_p(ptr), n, n, ncap, dev, C.byref(self.out)))
+        return self.out
+
+    # -- results
+    def fetch_frames(self):
+        n = C.c_size_t()
+        rc = self._L.sdr_fetch_frames(self._h, None, 0, C.byref(n))
+        _lib.check(self._h, rc)
+        if n.value == 0:
+            return []
+        buf = (_lib.Frame * n.value)()
+        _lib.check(self._h, self._L.sdr_fetch_frames(self._h, buf, n.value, C.byref(n)))
+        return [buf[i] for i in range(n.value)]
+
+    def fetch_bits(self):
+        n = C.c_size_t()
+        _lib.check(self._h, self._L.sdr_fetch_bits(self._h, None, 0, C.byref(n)))
+        out = np.zeros(n.value, np.int8)
+        if n.value:
+            _lib.check(self._h, self._L.sdr_fetch_bits(self._h, C.c_void_p(out.ctypes.data), out.size, C.byref(n)))
+        return out
+
+    def fetch_demod(self):
+        n = C.c_size_t()
+        _lib.check(self._h, self._L.sdr_fetch_demod(self._h, None, 0, C.byref(n)))
+        out = np.zeros(n.value, np.float32)
+        if n.value:
+            _lib.check(self._h, self._L.sdr_fetch_demod(self._h, C.c_void_p(out.ctypes.data), out.size, C.byref(n)))
+        return out.view(np.complex64) if self.cfg.demod == DEMOD_NONE else out
+
+    def decoder_state(self):
+        st = (C.c_int32 * 4)()
+        _lib.check(self._h, self._L.sdr_decoder_state(self._h, C.byref(st)))
+        return list(st)
+
+    # -- timing on the stream the kernels run on
+    def timer_start(self):
+        _lib.check(self._h, self._L.sdr_timer_start(self._h))
+
+    def timer_stop(self):
+        _lib.check(self._h, self._L.sdr_timer_stop(self._h))
+
+    def timer_elapsed_ms(self):
+        ms = C.c_float()
+        _lib.check(self._h, self._L.sdr_timer_elapsed_ms(self._h, C.byref(ms)))
+        return ms.value

@@ -1,0 +1,697 @@
+// Back-end kernel: one workgroup per capture (or per stream call).
+//   phase 0  resolve the hysteresis carry of every front-end tile and patch the
+//            bits that were emitted before a tile's first event;
+//   phase 1  run-length: positions where the sliced byte stream changes level
+//            (per-thread count -> block scan -> compaction);
+//   phase 2  the stream decoder's state machine over the run widths and the
+//            per-packet decode.
+// Integer / float64 work on a few hundred symbols per capture: latency-bound,
+// not bandwidth-bound; its traffic (1/(D*keep_n) B per input sample) is noise
+// beside the front end's 8 B.
+#pragma once
+#include "sdr_common.h"
+
+#define BK_THREADS 256
+#define SDR_HD __host__ __device__
+
+SDR_HD inline double run_width(const int32_t* __restrict__ pos, long long k, double rate)
+{
+    // np.diff(edge_positions)*1e6/self.sample_rate (TS33C/stream_decoder.py:74)
+    return (double)(pos[k + 1] - pos[k]) * 1e6 / rate;
+}
+
+// ---- numpy helpers restated on the device (float64, IEEE ops only) -----------
+
+SDR_HD inline void insertion_sort(double* a, int n)
+{
+    for (int i = 1; i < n; ++i) {
+        double v = a[i];
+        int j = i - 1;
+        while (j >= 0 && a[j] > v) {
+            a[j + 1] = a[j];
+            --j;
+        }
+        a[j + 1] = v;
+    }
+}
+
+// np.percentile(x, q*100) method 'linear' on sorted s (numpy/lib/_function_base_impl.py _quantile/_lerp)
+SDR_HD inline double pct_sorted(const double* s, int n, double q)
+{
+    double vi = (double)(n - 1) * q;
+    double fl = floor(vi);
+    int prev = (int)fl, next = prev + 1;
+    double g = vi - fl;
+    if (vi >= (double)(n - 1)) prev = next = n - 1;
+    if (vi < 0) prev = next = 0;
+    if (next > n - 1) next = n - 1;
+    double a = s[prev], b = s[next];
+    double d = b - a;
+    return (g >= 0.5) ? (b - d * (1.0 - g)) : (a + d * g);
+}
+
+// edges[edges.size//2] of np.histogram(x, "auto")[1]  (numpy 2.2.6 _hist_bin_auto,
+// _get_bin_edges, linspace).  s = sorted copy of x.
+SDR_HD inline double hist_auto_mid_edge(const double* s, int n, const double* __restrict__ pow_m13,
+                                            const double* __restrict__ log2n)
+{
+    if (n == 0) return 1.0;  // empty -> one bin on [0, 1]
+    double first = s[0], last = s[n - 1];
+    double ptp = last - first;
+    double iqr = pct_sorted(s, n, 0.75) - pct_sorted(s, n, 0.25);
+    int nt = n < SDR_MAX_POW_TABLE ? n : SDR_MAX_POW_TABLE - 1;
+    double fd = 2.0 * iqr * pow_m13[nt];
+    double stg = ptp / (log2n[nt] + 1.0);
+    double width = (fd != 0.0) ? ((stg < fd) ? stg : fd) : stg;
+    if (first == last) {
+        first = first - 0.5;
+        last = last + 0.5;
+    }
+    long long nb = 1;
+    if (width != 0.0) nb = (long long)ceil((last - first) / width);
+    if (nb < 1) nb = 1;
+    long long idx = (nb + 1) / 2;
+    if (idx == nb) return last;
+    double delta = last - first;
+    double step = delta / (double)nb;
+    if (step == 0.0) return ((double)idx / (double)nb) * delta + first;
+    return (double)idx * step + first;
+}
+
+// np.add.reduce pairwise summation for n < 128 contiguous float64 (numpy/_core/src/umath/loops_utils.h.src)
+SDR_HD inline double np_pairwise_sum_small(const double* a, int n)
+{
+    if (n < 8) {
+        double res = 0.0;  // numpy: res = 0.; for i: res += a[i]  (n<8 branch starts from 0.)
+        for (int i = 0; i < n; ++i) res += a[i];
+        return res;
+    }
+    double r[8];
+    for (int j = 0; j < 8; ++j) r[j] = a[j];
+    int i;
+    for (i = 8; i < n - (n % 8); i += 8)
+        for (int j = 0; j < 8; ++j) r[j] += a[i + j];
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; ++i) res += a[i];
+    return res;
+}
+
+SDR_HD inline void frame_init(sdr_frame* f, int cap, int dec, long long end_pos)
+{
+    f->capture = cap;
+    f->decoder = dec;
+    f->status = 0;
+    f->nbits = 0;
+    f->nbytes = 0;
+    for (int i = 0; i < 16; ++i) f->bytes[i] = 0;
+    for (int i = 0; i < 8; ++i) f->raw[i] = 0;
+    for (int i = 0; i < 4; ++i) f->v[i] = 0;
+    f->temp_tenths = 0;
+    f->pad_ = 0;
+    f->lim[0] = f->lim[1] = 0.0;
+    f->end_pos = end_pos;
+}
+
+// ---- TS33C packet decode (TS33C/stream_decoder.py:112-202) -------------------
+SDR_HD inline void decode_ts33c(const double* cur, int n, double reset_limit, double* scratch,
+                                    DecState* st, const BackParams& P, sdr_frame* f)
+{
+    int np_ = (n + 1) / 2, ng = n / 2;
+    // pulses = cur[0::2] -> histogram
+    for (int i = 0; i < np_; ++i) scratch[i] = cur[2 * i];
+    insertion_sort(scratch, np_);
+    double plim = hist_auto_mid_edge(scratch, np_, P.pow_m13, P.log2n);
+    // gaps = cur[1::2], packet pause -> 0, histogram over gaps > 0
+    int ngf = 0;
+    for (int i = 0; i < ng; ++i) {
+        double g = cur[2 * i + 1];
+        if (g > reset_limit) g = 0.0;
+        if (g > 0.0) scratch[ngf++] = g;
+    }
+    insertion_sort(scratch, ngf);
+    double glim = hist_auto_mid_edge(scratch, ngf, P.pow_m13, P.log2n);
+    st->pulse_short_limit = plim;
+    st->gap_short_limit = glim;
+    f->lim[0] = plim;
+    f->lim[1] = glim;
+
+    // rawBits -> parity / packet bits; bytes and per-byte parity on the fly
+    int nraw = 0, ndata = 0, npar = 0, ones = 0;
+    bool par_ok = true;
+    unsigned char bytes[16];
+    for (int i = 0; i < 16; ++i) bytes[i] = 0;
+    for (int k = 0; k < n; ++k) {
+        int bit;
+        if ((k & 1) == 0) {
+            bit = (cur[k] < plim) ? 1 : 0;
+        } else {
+            double g = cur[k];
+            if (g > reset_limit) g = 0.0;
+            if (g < glim) continue;  // short gap (255) removed
+            bit = 0;
+        }
+        ++nraw;
+        if (nraw % 9 == 0) {
+            // parity bit of the byte just completed: True iff popcount(byte) is even
+            bool even = (ones & 1) == 0;
+            if (even != (bit == 1)) par_ok = false;
+            ones = 0;
+            ++npar;
+        } else {
+            int byte = ndata >> 3, j = ndata & 7;
+            if (!bit) {  // reverse + invert
+                ++ones;
+                if (byte < 16) bytes[byte] |= (unsigned char)(1u << j);
+            }
+            ++ndata;
+        }
+    }
+    f->nbits = nraw;
+    if ((ndata % 8) != 0) {
+        f->status = SDR_FRAME_BAD_LENGTH;
+        return;
+    }
+    int nbytes = ndata / 8;
+    f->nbytes = nbytes < 16 ? nbytes : 16;
+    for (int i = 0; i < f->nbytes; ++i) f->bytes[i] = bytes[i];
+    // np.array_equal(packetParity, parityBits): same length and all equal
+    if (npar != nbytes || !par_ok) {
+        f->status = SDR_FRAME_PARITY;
+        return;
+    }
+    if (!(nbytes == 10 && bytes[0] == 0x9f)) {
+        f->status = SDR_FRAME_UNKNOWN_HEADER;
+        return;
+    }
+    int channel = (bytes[1] >> 5) & 0x0F;
+    if (channel >= 5) channel -= 1;
+    int temp = (bytes[5] & 0x0F) * 100 + ((bytes[4] & 0xF0) >> 4) * 10 + (bytes[4] & 0x0F);
+    int sign = (((bytes[5] >> 7) & 0x01) * 2) - 1;
+    f->v[0] = channel;
+    f->v[1] = bytes[1] & 0x0F;
+    f->v[2] = ((bytes[5] >> 6) & 0x01) == 1;
+    f->v[3] = ((bytes[6] & 0xF0) >> 4) * 10 + (bytes[6] & 0x0F);
+    f->temp_tenths = temp * sign;
+    f->status = SDR_FRAME_OK;
+}
+
+// ---- TFA packet decode (TFA/stream_decoder.py:132-199, analyzer2.grc:891-960) --
+SDR_HD inline unsigned char crc8_31(const unsigned char* d, int n)
+{
+    unsigned int crc = 0;
+    for (int i = 0; i < n; ++i) {
+        crc ^= d[i];
+        for (int b = 0; b < 8; ++b) crc = (crc & 0x80) ? (((crc << 1) ^ 0x31) & 0xFF) : ((crc << 1) & 0xFF);
+    }
+    return (unsigned char)crc;
+}
+
+SDR_HD inline void decode_tfa(const double* cur0, int n0, double* scratch, bool nan_guard, sdr_frame* f)
+{
+    // self.currentSymbols = self.currentSymbols[6:]
+    const double* c = cur0 + (n0 < 6 ? n0 : 6);
+    int n = n0 < 6 ? 0 : n0 - 6;
+    int ns = n < 150 ? n : 150;
+    if (ns & 1) {
+        f->status = SDR_FRAME_EXC_RESHAPE;
+        return;
+    }
+    int npair = ns / 2;
+    if (npair == 0) {
+        f->status = nan_guard ? SDR_FRAME_SYMBOL_LENGTH : SDR_FRAME_EXC_NAN;
+        return;
+    }
+    for (int i = 0; i < npair; ++i) scratch[i] = c[2 * i] + c[2 * i + 1];
+    double sym = np_pairwise_sum_small(scratch, npair) / (double)npair;
+    f->lim[0] = sym;
+    double thr = sym * 1.5;
+    int ds = -1;
+    for (int k = 0; k < n; ++k)
+        if (c[k] > thr) {
+            ds = k;
+            break;
+        }
+    if (ds < 0) {
+        f->status = SDR_FRAME_EXC_INDEX;
+        return;
+    }
+    unsigned char bytes[11];
+    for (int i = 0; i < 11; ++i) bytes[i] = 0;
+    long long nbits = 0;
+    for (int k = ds; k < n - 1; ++k) {
+        double w = c[k];
+        long long cnt;
+        int one = ((k - ds) & 1) == 0;
+        if (one) {
+            if (w < sym) w = 0.0;
+            cnt = (long long)floor(w / sym);
+        } else
+            cnt = (long long)ceil(w / sym);
+        if (one) {
+            for (long long i = 0; i < cnt && nbits + i < 88; ++i) {
+                long long b = nbits + i;
+                bytes[b >> 3] |= (unsigned char)(1u << (b & 7));  // per-byte bit reversal == LSB first
+            }
+        }
+        nbits += cnt;
+    }
+    f->nbits = (int)(nbits > 0x7fffffff ? 0x7fffffff : nbits);
+    if (nbits < 88) {
+        f->status = SDR_FRAME_BAD_LENGTH;
+        return;
+    }
+    f->nbytes = 11;
+    for (int i = 0; i < 11; ++i) f->bytes[i] = bytes[i];
+    if (crc8_31(bytes + 2, 8) != bytes[10]) {
+        f->status = SDR_FRAME_CRC;
+        return;
+    }
+    f->v[0] = ((int)bytes[2] << 8) + bytes[3];
+    f->v[1] = bytes[6] & 0x7f;
+    f->v[2] = ((bytes[7] >> 7) & 0x01) == 0;
+    f->temp_tenths = (bytes[4] & 0x0f) * 100 + ((bytes[5] >> 4) & 0x0f) * 10 + (bytes[5] & 0x0f) - 400;
+    f->status = SDR_FRAME_OK;
+}
+
+// ---- pigpio-callback rule decoders on run boundaries ---------------------------
+struct EdgeCtx {
+    const int32_t* pos;
+    long long R;
+    long long nb;
+    int first_level;
+    long long rate_hz;
+};
+SDR_HD inline long long tick_of(const EdgeCtx& e, long long k)
+{
+    return ((long long)e.pos[k] * 1000000LL) / e.rate_hz;
+}
+
+SDR_HD inline bool in_range(long long d, long long a, long long b) { return d >= a && d < b; }
+
+SDR_HD inline sdr_frame* next_frame(const BackParams& P, DecState* st, int cap, long long end_pos)
+{
+    if (st->n_frames >= P.max_frames) {
+        st->overflow |= 2;
+        return nullptr;
+    }
+    sdr_frame* f = P.frames + (long long)cap * P.max_frames + st->n_frames;
+    st->n_frames++;
+    frame_init(f, cap, P.decoder, end_pos);
+    return f;
+}
+
+// somfy/sniff.py:28-117
+SDR_HD inline void rule_somfy(const EdgeCtx& e, const BackParams& P, DecState* st, int cap,
+                                  unsigned char* bits /* >= 512 */)
+{
+    const int tol = 100;
+    long long start_tick = 0;
+    int state = 0, nbits = 0, clock = 640, n_sync = 0;
+    double sync_sum = 0.0;  // np.average of <8 values: sequential sum
+    const long long wd = 20000;
+    long long prev_tick = 0;
+    auto watchdog = [&](long long at_run) {
+        if (state > 0) {
+            // bits = bits[1:]; pad one zero if short
+            int n = nbits > 0 ? nbits - 1 : 0;
+            unsigned char* b = bits + (nbits > 0 ? 1 : 0);
+            if (n < 112 && n + 1 < 512) b[n++] = 0;
+            if (n == 112) {
+                sdr_frame* f = next_frame(P, st, cap, at_run);
+                if (f) {
+                    unsigned char fr[7];
+                    for (int i = 0; i < 7; ++i) fr[i] = 0;
+                    // np.where(reshape(bits,(-1,2)) == [0,1], 1, 0).ravel()[::2]: first half-symbol == 0
+                    for (int i = 0; i < 56; ++i)
+                        if (b[2 * i] == 0) fr[i >> 3] |= (unsigned char)(0x80u >> (i & 7));
+                    for (int i = 0; i < 7; ++i) f->raw[i] = fr[i];
+                    for (int i = 6; i > 0; --i) fr[i] = fr[i] ^ fr[i - 1];
+                    unsigned int ck = 0;
+                    for (int i = 0; i < 7; ++i) ck ^= fr[i] ^ (fr[i] >> 4);
+                    ck &= 0xf;
+                    f->nbits = 112;
+                    f->nbytes = 7;
+                    for (int i = 0; i < 7; ++i) f->bytes[i] = fr[i];
+                    f->v[0] = (fr[1] >> 4) & 0x0f;
+                    f->v[1] = ((int)fr[2] << 8) | fr[3];
+                    f->v[2] = (int)fr[4] | ((int)fr[5] << 8) | ((int)fr[6] << 16);
+                    f->v[3] = clock;
+                    f->status = ck == 0 ? SDR_FRAME_OK : SDR_FRAME_CHECKSUM;
+                }
+            }
+            nbits = 0;
+            state = 0;
+        }
+    };
+    auto push = [&](int v, int cnt) {
+        for (int i = 0; i < cnt; ++i)
+            if (nbits < 512) bits[nbits++] = (unsigned char)v;
+    };
+    auto event = [&](int level, long long tick) {
+        long long delta = tick - start_tick;
+        start_tick = tick;
+        if (level == 1) {  // end of gap
+            if (state <= 2 && in_range(delta, 2500 - 2 * tol, 2500 + 2 * tol)) {
+                if (state < 2) {
+                    n_sync = 0;
+                    sync_sum = 0.0;
+                }
+                sync_sum += (double)delta;
+                ++n_sync;
+                state = 2;
+            } else if (state == 3 && in_range(delta, 2 * clock - tol, 2 * clock + tol))
+                push(0, 2);
+            else if (state == 3 && in_range(delta, clock - tol, clock + tol))
+                push(0, 1);
+        } else {  // end of pulse
+            if (state == 0 && in_range(delta, 10050 - tol, 10050 + tol))
+                state = 1;
+            else if (state <= 2 && in_range(delta, 2500 - 2 * tol, 2500 + 2 * tol)) {
+                if (state < 2) {
+                    n_sync = 0;
+                    sync_sum = 0.0;
+                }
+                sync_sum += (double)delta;
+                ++n_sync;
+                state = 2;
+            } else if (state == 2 && in_range(delta, 4850 - 2 * tol, 4850 + 2 * tol)) {
+                clock = (int)((sync_sum / (double)n_sync) / 4.0);
+                nbits = 0;
+                state = 3;
+            } else if (state == 3 && in_range(delta, 2 * clock - tol, 2 * clock + tol))
+                push(1, 2);
+            else if (state == 3 && in_range(delta, clock - tol, clock + tol))
+                push(1, 1);
+        }
+    };
+    int level = e.first_level;
+    if (level == 1) event(1, 0);
+    for (long long k = 1; k < e.R; ++k) {
+        long long tick = tick_of(e, k);
+        if (tick - prev_tick > wd) watchdog(e.pos[k]);
+        level ^= 1;
+        event(level, tick);
+        prev_tick = tick;
+    }
+    long long end_tick = (e.nb * 1000000LL) / e.rate_hz;
+    if (end_tick - prev_tick > wd) watchdog(e.nb);
+}
+
+// berner/sniff.py:21-44
+SDR_HD inline void rule_berner(const EdgeCtx& e, const BackParams& P, DecState* st, int cap,
+                                   unsigned char* bits)
+{
+    long long start_tick = 0;
+    int state = 0, nbits = 0;
+    int level = e.first_level;
+    auto event = [&](int lvl, long long tick, long long at) {
+        if (lvl == 1)
+            start_tick = tick;
+        else {
+            long long delta = tick - start_tick;
+            if (state == 0 && delta > 5300 && delta < 5700) {
+                nbits = 0;
+                state = 1;
+            } else if (state == 1 && delta < 500) {
+                if (nbits < 512) bits[nbits++] = 0;
+            } else if (state == 1 && delta > 500 && delta < 1000) {
+                if (nbits < 512) bits[nbits++] = 1;
+            } else if (state == 1) {
+                if (nbits >= 32) {
+                    sdr_frame* f = next_frame(P, st, cap, at);
+                    if (f) {
+                        for (int i = 0; i < 32; ++i)
+                            if (bits[i]) f->bytes[i >> 3] |= (unsigned char)(0x80u >> (i & 7));
+                        f->nbits = nbits;
+                        f->nbytes = 4;
+                        f->status = SDR_FRAME_OK;
+                    }
+                }
+                state = 0;
+            }
+        }
+    };
+    if (level == 1) event(1, 0, 0);
+    for (long long k = 1; k < e.R; ++k) {
+        level ^= 1;
+        event(level, tick_of(e, k), e.pos[k]);
+    }
+}
+
+// mumbi/sniff.py:26-65 (watchdog 8 ms)
+SDR_HD inline void rule_mumbi(const EdgeCtx& e, const BackParams& P, DecState* st, int cap,
+                                  unsigned char* bits)
+{
+    const int tol = 50;
+    const long long wd = 8000;
+    long long start_tick = 0, prev_tick = 0;
+    int state = 0, nbits = 0;
+    int level = e.first_level;
+    auto watchdog = [&](long long at) {
+        if (state > 0) {
+            if (nbits == 34) {
+                sdr_frame* f = next_frame(P, st, cap, at);
+                if (f) {
+                    for (int i = 0; i < 34; ++i)
+                        if (bits[i]) f->bytes[i >> 3] |= (unsigned char)(0x80u >> (i & 7));
+                    f->nbits = 34;
+                    f->nbytes = 5;
+                    f->status = SDR_FRAME_OK;
+                }
+            }
+            nbits = 0;
+            state = 0;
+        }
+    };
+    auto event = [&](int lvl, long long tick) {
+        if (lvl == 1)
+            start_tick = tick;
+        else {
+            long long delta = tick - start_tick;
+            if (in_range(delta, 820 - 2 * tol, 820 + 2 * tol)) {
+                if (nbits < 512) bits[nbits++] = 1;
+                state = 1;
+            } else if (in_range(delta, 300 - tol, 300 + tol)) {
+                if (nbits < 512) bits[nbits++] = 0;
+            }
+        }
+    };
+    if (level == 1) event(1, 0);
+    for (long long k = 1; k < e.R; ++k) {
+        long long tick = tick_of(e, k);
+        if (tick - prev_tick > wd) watchdog(e.pos[k]);
+        level ^= 1;
+        event(level, tick);
+        prev_tick = tick;
+    }
+    long long end_tick = (e.nb * 1000000LL) / e.rate_hz;
+    if (end_tick - prev_tick > wd) watchdog(e.nb);
+}
+
+// ---- the stream decoder front end (TS33C/stream_decoder.py:39-110,204-217) ----
+SDR_HD inline void stream_decode(const BackParams& P, int cap, const int32_t* pos, long long R,
+                                     int first_level, int last_level, bool any_one, double* cur,
+                                     DecState* st, double* cur_lds, double* scratch)
+{
+    const bool ts33c = (P.decoder == SDR_DEC_TS33C);
+    const double reset_limit = ts33c ? 1550.0 : 500.0;
+    // skip empty or zero-only chunks (:50)
+    if (!(P.nb > 0 && (any_one || st->n_cur > 0))) {
+        st->state = 0;
+        return;
+    }
+    const int cur_type = first_level;
+    st->chunk_id += 1;
+    // pieces end after every width > reset_limit (:77)
+    long long n_over = 0;
+    for (long long k = 0; k < R; ++k)
+        if (run_width(pos, k, P.dec_rate) > reset_limit) ++n_over;
+    const long long npieces = n_over + 1;
+    const bool size_is_1 = (npieces == 1 && R == 1);
+    if (npieces > 1) st->state = 1;
+    long long a = 0;
+    for (long long pc = 0; pc < npieces; ++pc) {
+        long long b = a;
+        if (pc == npieces - 1)
+            b = R;
+        else {
+            while (run_width(pos, b, P.dec_rate) <= reset_limit) ++b;
+            ++b;  // the over-limit width closes the piece
+        }
+        long long s = a;
+        if (size_is_1 || st->state == 0) ++s;  // skip leading inter-frame gap (:90-92)
+        if (s < b) {
+            st->state = 1;
+            if (st->n_cur > 0 && st->prev_type == cur_type) {  // (:98-100)
+                cur[st->n_cur - 1] += run_width(pos, s, P.dec_rate);
+                ++s;
+            }
+            for (long long k = s; k < b; ++k) {
+                if (st->n_cur < SDR_CUR_CAP)
+                    cur[st->n_cur++] = run_width(pos, k, P.dec_rate);
+                else
+                    st->overflow |= 4;
+            }
+            if (cur[0] > reset_limit) {  // (:104-105)
+                for (int i = 1; i < st->n_cur; ++i) cur[i - 1] = cur[i];
+                st->n_cur--;
+            }
+            if (st->n_cur > 1 && cur[st->n_cur - 1] > reset_limit) {  // (:110)
+                sdr_frame* f = next_frame(P, st, cap, pos[b]);
+                if (f) {
+                    int n = st->n_cur;
+                    for (int i = 0; i < n; ++i) cur_lds[i] = cur[i];
+                    if (ts33c)
+                        decode_ts33c(cur_lds, n, reset_limit, scratch, st, P, f);
+                    else
+                        decode_tfa(cur_lds, n, scratch, P.decoder == SDR_DEC_TFA_GRC, f);
+                }
+                st->n_cur = 0;  // done with this packet (:204)
+            }
+        } else {
+            st->state = 0;  // "skipping empty chunk" (:207-209)
+        }
+        a = b;
+    }
+    st->prev_type = last_level;  // rawBuffer[-2] (:212)
+}
+
+__global__ void __launch_bounds__(BK_THREADS) k_backend(BackParams P)
+{
+    __shared__ int s_cnt[BK_THREADS];
+    __shared__ int s_has[BK_THREADS];
+    __shared__ int s_last[BK_THREADS];
+    __shared__ double s_cur[SDR_CUR_CAP];
+    __shared__ double s_scratch[SDR_CUR_CAP];
+    __shared__ unsigned char s_bits[512];
+    __shared__ long long s_R;
+
+    const int cap = blockIdx.x, tid = threadIdx.x;
+    int8_t* bits = P.bits + (long long)cap * P.bits_stride;
+    DecState* st = P.st + cap;
+
+    if (P.fresh && tid == 0) {
+        st->state = 0;
+        st->n_cur = 0;
+        st->prev_type = 0;
+        st->chunk_id = 0;
+        st->thr_state = P.thr_init;
+        st->overflow = 0;
+        st->pulse_short_limit = 775.0;
+        st->gap_short_limit = 775.0;
+    }
+    if (tid == 0) st->n_frames = 0;
+    __syncthreads();
+
+    // ---- phase 0: hysteresis carries --------------------------------------
+    if (P.tsum) {
+        const TileSum* ts = P.tsum + (long long)cap * P.tiles_per_capture;
+        const int nt = P.tiles_per_capture;
+        const int per = (nt + BK_THREADS - 1) / BK_THREADS;
+        const int t0 = tid * per, t1 = (t0 + per < nt) ? t0 + per : nt;
+        int has = 0, last = 0;
+        for (int i = t0; i < t1; ++i)
+            if (ts[i].first_evt >= 0) {
+                has = 1;
+                last = ts[i].last_state;
+            }
+        s_has[tid] = has;
+        s_last[tid] = last;
+        __syncthreads();
+        int carry = P.use_state_thr ? st->thr_state : P.thr_init;
+        for (int w = tid - 1; w >= 0; --w)
+            if (s_has[w]) {
+                carry = s_last[w];
+                break;
+            }
+        int8_t* wbits = bits + P.patch_off;
+        for (int i = t0; i < t1; ++i) {
+            long long o_beg = (long long)i * P.tile_out;
+            long long o_end = min(P.nout, o_beg + P.tile_out);
+            long long fe = ts[i].first_evt;
+            if (carry == 1) {
+                long long e = fe >= 0 ? fe : o_end;
+                long long o = o_beg < P.keep_c0 ? P.keep_c0 : o_beg;
+                if (P.keep_n > 1) {
+                    long long r = (o - P.keep_c0) % P.keep_n;
+                    if (r) o += P.keep_n - r;
+                }
+                for (; o < e; o += P.keep_n) wbits[(o - P.keep_c0) / P.keep_n] = 1;
+            }
+            if (fe >= 0) carry = ts[i].last_state;
+        }
+        __syncthreads();
+        // thread that owns the last tile publishes the carry-out
+        if (t0 < nt && t1 == nt) st->thr_state = carry;
+        if (nt == 0 && tid == 0) st->thr_state = carry;
+    }
+    if (!P.run_decoder || P.decoder == SDR_DEC_NONE) return;
+    __syncthreads();
+
+    // ---- phase 1: run-length ------------------------------------------------
+    const long long nb = P.nb;
+    int32_t* pos = P.runs + (long long)cap * (P.runs_cap + 2);
+    const long long per = (nb + BK_THREADS - 1) / BK_THREADS;
+    const long long j0 = (long long)tid * per, j1 = min(nb, j0 + per);
+    int cnt = 0;
+    {
+        int prev = (j0 > 0 && j0 < nb) ? bits[j0 - 1] : (nb > 0 ? bits[0] : 0);
+        for (long long j = j0; j < j1; ++j) {
+            int b = bits[j];
+            cnt += (b != prev);
+            prev = b;
+        }
+    }
+    s_cnt[tid] = cnt;
+    __syncthreads();
+    if (tid == 0) {
+        int acc = 0;
+        for (int i = 0; i < BK_THREADS; ++i) {
+            int c = s_cnt[i];
+            s_cnt[i] = acc;
+            acc += c;
+        }
+        long long R = (long long)acc + 1;
+        if (nb == 0) R = 0;
+        if (R > P.runs_cap) {
+            st->overflow |= 1;
+            R = P.runs_cap;
+        }
+        s_R = R;
+        pos[0] = 0;
+    }
+    __syncthreads();
+    const long long R = s_R;
+    {
+        long long w = 1 + s_cnt[tid];
+        int prev = (j0 > 0 && j0 < nb) ? bits[j0 - 1] : (nb > 0 ? bits[0] : 0);
+        for (long long j = j0; j < j1; ++j) {
+            int b = bits[j];
+            if (b != prev) {
+                if (w < R) pos[w] = (int32_t)j;
+                ++w;
+            }
+            prev = b;
+        }
+    }
+    __syncthreads();
+    if (tid != 0) return;
+    pos[R] = (int32_t)nb;
+
+    // ---- phase 2: decode (one thread; a few hundred symbols) -----------------
+    if (nb == 0) return;
+    const int first_level = bits[0] != 0, last_level = bits[nb - 1] != 0;
+    const bool any_one = first_level || R > 1;
+    if (P.decoder <= SDR_DEC_TFA_GRC) {
+        stream_decode(P, cap, pos, R, first_level, last_level, any_one,
+                      P.cur + (long long)cap * SDR_CUR_CAP, st, s_cur, s_scratch);
+    } else {
+        EdgeCtx e{pos, R, nb, first_level, (long long)P.dec_rate};
+        if (P.decoder == SDR_DEC_SOMFY)
+            rule_somfy(e, P, st, cap, s_bits);
+        else if (P.decoder == SDR_DEC_BERNER)
+            rule_berner(e, P, st, cap, s_bits);
+        else if (P.decoder == SDR_DEC_MUMBI)
+            rule_mumbi(e, P, st, cap, s_bits);
+    }
+}

@@ -1,0 +1,267 @@
+// Front-end kernels: NCO + decimating FIR + demod + gain + hysteresis + slicer
+// + keep_one_in_n fused in one pass over the IQ samples (SURVEY.md 8a rows
+// a1, a2, a4, a5, a8).  HBM-bound for D >~ 16: 8 B read per input sample,
+// 1/(D*keep_n) B written.  Arithmetic order is the oracle's (oracle/dsp_oracle.c
+// header): one fmaf per tap and lane, oldest sample first.
+#pragma once
+#include "sdr_common.h"
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+// exact-phase NCO: see orc nco64 in oracle/dsp_oracle.c (same op sequence)
+__device__ __forceinline__ float2 nco_eval(const float2* __restrict__ tab, unsigned long long ph)
+{
+    unsigned int u = (unsigned int)(ph >> 32);
+    unsigned int i = u >> 22;
+    float r = (float)(u & 0x3fffffu) * 1.46291807926715968105e-9f;
+    float r2 = r * r;
+    float cr = __builtin_fmaf(r2, __builtin_fmaf(r2, 4.16666666666666666667e-2f, -0.5f), 1.0f);
+    float sr = r * __builtin_fmaf(r2, __builtin_fmaf(r2, 8.33333333333333333333e-3f, -1.66666666666666666667e-1f), 1.0f);
+    float2 t = tab[i];
+    float2 o;
+    o.x = __builtin_fmaf(t.x, cr, -(t.y * sr));
+    o.y = __builtin_fmaf(t.y, cr, t.x * sr);
+    return o;
+}
+
+// gnuradio fast_atan2f restated (table 257 floats), same op order as the oracle
+__device__ __forceinline__ float fast_atan2f_dev(const float* __restrict__ tab, float y, float x)
+{
+    float y_abs = __builtin_fabsf(y), x_abs = __builtin_fabsf(x), z, base;
+    if (!((y_abs > 0.0f) || (x_abs > 0.0f))) return 0.0f;
+    if (y_abs < x_abs)
+        z = y_abs / x_abs;
+    else
+        z = x_abs / y_abs;
+    if (z < 0.003921569f)
+        base = z;
+    else {
+        float alpha = z * 255.0f;
+        int index = ((int)alpha) & 0xff;
+        alpha -= (float)index;
+        base = tab[index];
+        base += (tab[index + 1] - tab[index]) * alpha;
+    }
+    float angle;
+    if (x_abs > y_abs) {
+        if (x >= 0.0f)
+            angle = (y >= 0.0f) ? base : -base;
+        else {
+            angle = 3.14159265358979323846f;
+            if (y >= 0.0f)
+                angle -= base;
+            else
+                angle = base - angle;
+        }
+    } else {
+        if (y >= 0.0f) {
+            angle = 1.57079632679489661923f;
+            if (x >= 0.0f)
+                angle -= base;
+            else
+                angle += base;
+        } else {
+            angle = -1.57079632679489661923f;
+            if (x >= 0.0f)
+                angle += base;
+            else
+                angle -= base;
+        }
+    }
+    return angle;
+}
+
+// Hysteresis (threshold_ff) inside one tile as a scan over {set, clear, hold}
+// events: wavefront ballots + a <=4-entry cross-wave table.  Outputs before the
+// tile's first event take the carry-in, assumed 0 here and patched by the
+// back-end kernel once the carry of every tile is known.  Then the slicer
+// (state - 0.5 >= 0 == state) and keep_one_in_n.
+__device__ __forceinline__ void slice_tile(bool valid, float v, long long o, long long o_base, float lo, float hi,
+                                           int keep_n, long long keep_c0, int8_t* __restrict__ bits,
+                                           TileSum* __restrict__ ts_out, int* __restrict__ sh /* 12 ints */)
+{
+    int evt = valid ? (v > hi ? 1 : (v < lo ? 2 : 0)) : 0;
+    unsigned long long sset = __ballot(evt == 1);
+    unsigned long long sclr = __ballot(evt == 2);
+    unsigned long long any = sset | sclr;
+    int lane = lane_id(), wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    if (lane == 0) {
+        sh[wave] = any != 0;
+        sh[4 + wave] = any ? (int)((sset >> (63 - __builtin_clzll(any))) & 1) : 0;
+        sh[8 + wave] = any ? (wave * 64 + __builtin_ctzll(any)) : -1;
+    }
+    __syncthreads();
+    unsigned long long below = any & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
+    int st = 0;
+    if (below) {
+        int idx = 63 - __builtin_clzll(below);
+        st = (int)((sset >> idx) & 1);
+    } else {
+        for (int w = wave - 1; w >= 0; --w)
+            if (sh[w]) {
+                st = sh[4 + w];
+                break;
+            }
+    }
+    if (threadIdx.x == 0) {
+        int first = -1, last = 0;
+        for (int w = 0; w < nw; ++w)
+            if (sh[w]) {
+                if (first < 0) first = sh[8 + w];
+                last = sh[4 + w];
+            }
+        // first_evt as output index: thread index -> o of thread 0 + index
+        ts_out->first_evt = first < 0 ? -1 : (int32_t)(o_base + first);
+        ts_out->last_state = last;
+    }
+    if (valid && o >= keep_c0) {
+        long long r = o - keep_c0;
+        if (keep_n == 1)
+            bits[r] = (int8_t)st;
+        else if (r % keep_n == 0)
+            bits[r / keep_n] = (int8_t)st;
+    }
+}
+
+// One thread = one FIR output.  Tile = blockDim.x consecutive FIR outputs whose
+// (T-1)*D + ntaps input samples are staged once in LDS (coalesced 8-B loads),
+// then every thread walks its ntaps-window with ds_read_b64 + 2 (4) fmaf.
+// QUAD demod needs y[m-1]: thread t computes y[o0-1+t] and emits for t>=1.
+template <bool USE_LDS>
+__global__ void __launch_bounds__(256) k_frontend(FrontParams P)
+{
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    float2* lds = reinterpret_cast<float2*>(smem_raw);
+    __shared__ int sh[12];
+    __shared__ float2 ysh[256];
+
+    const int T = blockDim.x;
+    const int tile = blockIdx.x, cap = blockIdx.y;
+    const int q = (P.demod == SDR_DEMOD_QUAD) ? 1 : 0;
+    const long long o0 = (long long)tile * P.tile_out;
+    const long long m_t0 = o0 - q;                       // FIR output index of thread 0
+    const float2* __restrict__ x = P.x + (long long)cap * P.stride;
+    const int H = P.ntaps - 1;
+    const long long lo_idx = P.in0 + m_t0 * P.D - H;     // first input sample of the tile
+    const int count = (T - 1) * P.D + P.ntaps;
+
+    auto fetch = [&](long long idx) -> float2 {
+        if (idx >= 0) return idx < P.n ? x[idx] : make_float2(0.f, 0.f);
+        if (P.hist && idx >= -(long long)P.hist_len) return P.hist[P.hist_len + idx];
+        return make_float2(0.f, 0.f);
+    };
+
+    if (USE_LDS) {
+        for (int i = threadIdx.x; i < count; i += T) lds[i] = fetch(lo_idx + i);
+        __syncthreads();
+    }
+
+    const int t = threadIdx.x;
+    const long long m = m_t0 + t;
+    const long long o = m;          // demod output index == FIR output index (emitted for t>=q)
+    bool have_y = (m >= 0 || P.hist != nullptr) && (m < P.nout);
+    // m == -1 in streaming mode: previous call's last output, recomputed from history
+    float ar = 0.f, ai = 0.f;
+    if (have_y) {
+        const float* __restrict__ rt = P.rtaps;
+        if (USE_LDS) {
+            const float2* p = lds + (long long)t * P.D;
+            if (P.taps_complex) {
+                for (int j = 0; j < P.ntaps; ++j) {
+                    float2 s = p[j];
+                    float tr = rt[2 * j], ti = rt[2 * j + 1];
+                    ar = __builtin_fmaf(tr, s.x, ar);
+                    ar = __builtin_fmaf(-ti, s.y, ar);
+                    ai = __builtin_fmaf(tr, s.y, ai);
+                    ai = __builtin_fmaf(ti, s.x, ai);
+                }
+            } else {
+#pragma unroll 8
+                for (int j = 0; j < P.ntaps; ++j) {
+                    float2 s = p[j];
+                    float tp = rt[j];
+                    ar = __builtin_fmaf(tp, s.x, ar);
+                    ai = __builtin_fmaf(tp, s.y, ai);
+                }
+            }
+        } else {
+            long long base = lo_idx + (long long)t * P.D;
+            for (int j = 0; j < P.ntaps; ++j) {
+                float2 s = fetch(base + j);
+                if (P.taps_complex) {
+                    float tr = rt[2 * j], ti = rt[2 * j + 1];
+                    ar = __builtin_fmaf(tr, s.x, ar);
+                    ar = __builtin_fmaf(-ti, s.y, ar);
+                    ai = __builtin_fmaf(tr, s.y, ai);
+                    ai = __builtin_fmaf(ti, s.x, ai);
+                } else {
+                    float tp = rt[j];
+                    ar = __builtin_fmaf(tp, s.x, ar);
+                    ai = __builtin_fmaf(tp, s.y, ai);
+                }
+            }
+        }
+        if (P.nco_tab) {
+            float2 r = nco_eval(P.nco_tab, (P.nco_m0 + (unsigned long long)m) * P.nco_inc);
+            float yr = __builtin_fmaf(ar, r.x, -(ai * r.y));
+            float yi = __builtin_fmaf(ar, r.y, ai * r.x);
+            ar = yr;
+            ai = yi;
+        }
+    }
+
+    bool valid = (t >= q) && (o < P.nout) && (t - q < P.tile_out);
+    float v = 0.f;
+    if (P.demod == SDR_DEMOD_NONE) {
+        if (valid && P.tap)
+            reinterpret_cast<float2*>(P.tap + (long long)cap * P.tap_stride)[o] = make_float2(ar, ai);
+        return;
+    } else if (P.demod == SDR_DEMOD_MAG2) {
+        v = __builtin_fmaf(ar, ar, ai * ai);
+    } else {
+        ysh[t] = make_float2(ar, ai);
+        __syncthreads();
+        if (valid) {
+            float2 pv = ysh[t - 1];
+            float tr = __builtin_fmaf(ar, pv.x, ai * pv.y);
+            float ti = __builtin_fmaf(ai, pv.x, -(ar * pv.y));
+            v = fast_atan2f_dev(P.atan_tab, ti, tr);
+        }
+    }
+    v = P.gain * v;
+    if (valid && P.tap) (P.tap + (long long)cap * P.tap_stride)[o] = v;
+    if (!P.do_slice) return;
+    // slice_tile wants the output index of thread 0 (= o0 - q)
+    slice_tile(valid, v, o, o - t, P.lo, P.hi, P.keep_n, P.keep_c0,
+               P.bits + (long long)cap * P.bits_stride,
+               P.tsum + (long long)cap * P.tiles_per_capture + tile, sh);
+}
+
+// Real FIR (decimation 1) on demodulated floats + gain + slicer:
+// TFA/analyzer2.grc:1075-1147 low_pass_filter (fff) between mag^2 and threshold.
+__global__ void __launch_bounds__(256) k_post_fir_slice(PostParams P)
+{
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    float* lds = reinterpret_cast<float*>(smem_raw);
+    __shared__ int sh[12];
+    const int T = blockDim.x, tile = blockIdx.x, cap = blockIdx.y;
+    const long long o0 = (long long)tile * P.tile_out;
+    const float* __restrict__ v = P.v + (long long)cap * P.v_stride;
+    const int H = P.ntaps - 1;
+    const int count = T + H;
+    for (int i = threadIdx.x; i < count; i += T) {
+        long long idx = o0 - H + i;
+        lds[i] = (idx >= 0 && idx < P.nout) ? v[idx] : 0.f;
+    }
+    __syncthreads();
+    const int t = threadIdx.x;
+    const long long o = o0 + t;
+    bool valid = o < P.nout;
+    float a = 0.f;
+    if (valid)
+        for (int j = 0; j < P.ntaps; ++j) a = __builtin_fmaf(P.rtaps[j], lds[t + j], a);
+    if (valid && P.tap) (P.tap + (long long)cap * P.tap_stride)[o] = a;
+    float g = P.gain * a;
+    slice_tile(valid, g, o, o0, P.lo, P.hi, P.keep_n, P.keep_c0, P.bits + (long long)cap * P.bits_stride,
+               P.tsum + (long long)cap * P.tiles_per_capture + tile, sh);
+}

@@ -1,0 +1,105 @@
+// Internal declarations shared by the host side (sdr_host.cpp part of
+// sdrhip.hip) and the kernels.  Not part of the public ABI (include/sdrhip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/sdrhip.h"
+
+#define SDR_MAX_POW_TABLE 4096   // n^(-1/3), log2(n) tables for np.histogram "auto"
+#define SDR_CUR_CAP 2048         // pending symbols (currentSymbols) per stream
+#define SDR_NCO_TAB 1024
+
+// per-tile hysteresis summary written by the front-end kernels
+struct TileSum {
+    int32_t first_evt;   // demod-output index (within the capture/call) of the tile's first set/clear event, -1 if none
+    int32_t last_state;  // state after the tile's last event (valid iff first_evt >= 0)
+};
+
+// decoder state that persists between work() calls (ref: TS33C/stream_decoder.py:20-32)
+struct DecState {
+    int32_t state;          // 0 idle, 1 frame
+    int32_t n_cur;          // len(currentSymbols)
+    int32_t prev_type;      // previousSymbolType
+    int32_t chunk_id;
+    int32_t thr_state;      // threshold_ff state carried between streaming calls
+    int32_t n_frames;       // frames written by the last call
+    int32_t overflow;       // !=0: runs/frames/symbol table overflow
+    int32_t pad_;
+    double pulse_short_limit;
+    double gap_short_limit;
+};
+
+struct FrontParams {
+    const float2* x;        // capture 0, sample 0
+    const float2* hist;     // streaming: hist_len samples that precede x[0]; nullptr = zeros
+    long long stride;       // samples between captures
+    long long n;            // samples per capture readable at x
+    long long nout;         // demod outputs per capture in this call
+    long long in0;          // input index of output 0's newest sample
+    int hist_len;
+    int D;
+    int ntaps;
+    int taps_complex;
+    const float* rtaps;     // taps reversed (oldest-sample-first order); (re,im) pairs if complex
+    unsigned long long nco_inc;
+    unsigned long long nco_m0;  // absolute output index of output 0 (NCO phase origin)
+    const float2* nco_tab;  // nullptr = no rotation
+    const float* atan_tab;
+    int demod;
+    float gain, lo, hi;
+    int do_slice;           // 0: only write y/tap (a post-demod stage follows)
+    int keep_n;
+    long long keep_c0;      // first emitted output index (keep_one_in_n counter - 1)
+    int8_t* bits;
+    long long bits_stride;
+    float* tap;             // optional demod floats (nout per capture); float2 when demod==NONE
+    long long tap_stride;
+    TileSum* tsum;
+    int tiles_per_capture;
+    int tile_out;           // demod outputs per tile
+};
+
+struct PostParams {         // real FIR on demodulated floats + slicer (TFA/analyzer2.grc chain)
+    const float* v;         // nin floats per capture (zero history)
+    long long v_stride;
+    long long nout;
+    int ntaps;
+    const float* rtaps;
+    float gain, lo, hi;
+    int keep_n;
+    long long keep_c0;
+    int8_t* bits;
+    long long bits_stride;
+    float* tap;
+    long long tap_stride;
+    TileSum* tsum;
+    int tiles_per_capture;
+    int tile_out;
+};
+
+struct BackParams {
+    int8_t* bits;           // per capture bits_stride bytes
+    long long bits_stride;
+    long long nb;           // bytes to decode per capture (whole rawBuffer)
+    const TileSum* tsum;    // nullptr: bits are final (sdr_process_bits)
+    int tiles_per_capture;
+    int tile_out;
+    long long nout;         // demod outputs this call (for the last tile's extent)
+    int keep_n;
+    long long keep_c0;
+    long long patch_off;    // byte offset inside the capture's bits where this call's output starts (streaming append)
+    int thr_init;           // used when use_state_thr == 0
+    int use_state_thr;      // streaming: carry-in comes from DecState.thr_state
+    int run_decoder;        // 0: only resolve carries (rawBuffer still filling)
+    int decoder;
+    int fresh;              // batch: reset DecState per capture before decoding
+    double dec_rate;        // decoder sample_rate
+    int32_t* runs;          // per capture runs_cap+2 ints
+    long long runs_cap;
+    double* cur;            // per capture SDR_CUR_CAP doubles
+    DecState* st;           // per capture
+    sdr_frame* frames;      // per capture max_frames
+    int max_frames;
+    const double* pow_m13;  // n^(-1/3)
+    const double* log2n;    // log2(n)
+};

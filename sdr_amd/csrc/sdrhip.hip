@@ -1,0 +1,861 @@
+// libsdrhip.so -- host side of the C ABI declared in include/sdrhip.h.
+// gfx950 only.  Filter design (firdes), table set-up, buffer ownership, launch
+// geometry and the streaming state that the GNU Radio scheduler / the Python
+// decoder object keep between work() calls.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "sdr_common.h"
+#include "frontend_kernels.h"
+#include "backend_kernels.h"
+#include "fm_kernels.h"
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+struct sdr_handle {
+    sdr_chain_cfg cfg;
+    int device = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    std::string err;
+
+    std::vector<float> proto_taps;  // as given (real, or re/im pairs)
+    bool proto_complex = false;
+    int ntaps = 1;
+    bool rt_complex = false;
+    float* d_rtaps = nullptr;
+    std::vector<float> post_taps;
+    float* d_post_rtaps = nullptr;
+    float2* d_nco_tab = nullptr;
+    float* d_atan_tab = nullptr;
+    double* d_pow = nullptr;
+    double* d_log2 = nullptr;
+    unsigned long long nco_inc = 0;
+
+    float2* d_iq = nullptr;       // staging for host inputs
+    size_t iq_cap = 0;
+    float2* d_hist[2] = {nullptr, nullptr};
+    int hist_sel = 0, hist_len = 0, hist_cap = 0;
+    int8_t* d_bits = nullptr;
+    long long bits_stride = 0;
+    float* d_tap = nullptr;       // demod floats (or complex pairs)
+    float* d_tap2 = nullptr;      // post-filter output
+    long long tap_stride = 0;
+    TileSum* d_tsum = nullptr;
+    int tsum_stride = 0;
+    int32_t* d_runs = nullptr;
+    long long runs_cap = 0;
+    double* d_cur = nullptr;
+    DecState* d_st = nullptr;
+    sdr_frame* d_frames = nullptr;
+
+    // streaming state tracked on the host (pure functions of the sample counts)
+    unsigned long long in_count = 0, out_count = 0;
+    long long keep_ctr = 1;
+    long long raw_n = 0;
+    bool stream_started = false;
+
+    // last call
+    int last_ncap = 0;
+    long long last_nb = 0, last_nout = 0, last_bits_off = 0;
+    double dec_rate = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+static thread_local std::string g_err;
+
+static int fail(sdr_handle* h, int code, const std::string& msg)
+{
+    if (h) h->err = msg;
+    g_err = msg;
+    return code;
+}
+
+#define HIPCHK(h, call)                                                                       \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return fail(h, SDR_E_HIP, std::string(#call) + ": " + hipGetErrorString(e_));     \
+    } while (0)
+
+// ------------------------------------------------------------------ firdes
+// gr-filter/lib/firdes.cc low_pass + gr-fft/lib/window.cc (GNU Radio 3.7.11),
+// restated: float windows, float taps, double normalisation.
+static double izero(double x)
+{
+    double sum = 1, u = 1, halfx = x / 2.0, temp;
+    int n = 1;
+    do {
+        temp = halfx / (double)n;
+        n += 1;
+        temp *= temp;
+        u *= temp;
+        sum += u;
+    } while (u >= 1e-21 * sum);
+    return sum;
+}
+
+static bool make_window(int win, int ntaps, double beta, std::vector<float>& w)
+{
+    w.resize(ntaps);
+    const double M = ntaps - 1;
+    for (int n = 0; n < ntaps; ++n) {
+        switch (win) {
+        case SDR_WIN_HAMMING: w[n] = 0.54 - 0.46 * cos((2 * M_PI * n) / M); break;
+        case SDR_WIN_HANN: w[n] = 0.5 - 0.5 * cos((2 * M_PI * n) / M); break;
+        case SDR_WIN_BLACKMAN:
+            w[n] = 0.42 - 0.5 * cos((2 * M_PI * n) / M) + 0.08 * cos((4 * M_PI * n) / M);
+            break;
+        case SDR_WIN_RECTANGULAR: w[n] = 1; break;
+        case SDR_WIN_KAISER: {
+            double t = 2 * n * (1.0 / M) - 1;
+            w[n] = izero(beta * sqrt(1.0 - t * t)) * (1.0 / izero(beta));
+            break;
+        }
+        case SDR_WIN_BLACKMAN_HARRIS:
+            w[n] = 0.35875 - 0.48829 * cos((2 * M_PI * n) / M) + 0.14128 * cos((4 * M_PI * n) / M) -
+                   0.01168 * cos((6 * M_PI * n) / M);
+            break;
+        default: return false;
+        }
+    }
+    return true;
+}
+
+extern "C" int sdr_firdes_low_pass(double gain, double fs, double fc, double tw, int win, double beta,
+                                   float* taps, int cap)
+{
+    double a;
+    switch (win) {
+    case SDR_WIN_HAMMING: a = 53; break;
+    case SDR_WIN_HANN: a = 44; break;
+    case SDR_WIN_BLACKMAN: a = 74; break;
+    case SDR_WIN_RECTANGULAR: a = 21; break;
+    case SDR_WIN_KAISER: a = beta / 0.1102 + 8.7; break;
+    case SDR_WIN_BLACKMAN_HARRIS: a = 92; break;
+    default: return SDR_E_ARG;
+    }
+    if (!(fs > 0) || !(tw > 0) || !(fc > 0)) return SDR_E_ARG;
+    int ntaps = (int)(a * fs / (22.0 * tw));
+    if ((ntaps & 1) == 0) ntaps++;
+    if (ntaps > cap || !taps) return SDR_E_CAPACITY;
+    std::vector<float> w;
+    make_window(win, ntaps, beta, w);
+    const int M = (ntaps - 1) / 2;
+    const double fwT0 = 2 * M_PI * fc / fs;
+    for (int n = -M; n <= M; n++) {
+        if (n == 0)
+            taps[n + M] = fwT0 / M_PI * w[n + M];
+        else
+            taps[n + M] = sin(n * fwT0) / (n * M_PI) * w[n + M];
+    }
+    double fmax = taps[0 + M];
+    for (int n = 1; n <= M; n++) fmax += 2 * taps[n + M];
+    gain /= fmax;
+    for (int i = 0; i < ntaps; i++) taps[i] *= gain;
+    return ntaps;
+}
+
+extern "C" int sdr_resampler_taps(int interp, int decim, double fbw, float* taps, int cap)
+{
+    if (interp < 1 || decim < 1) return SDR_E_ARG;
+    int a = interp, b = decim;
+    while (b) {
+        int t = a % b;
+        a = b;
+        b = t;
+    }
+    interp /= a;
+    decim /= a;
+    if (fbw <= 0) fbw = 0.4;
+    const double beta = 7.0, halfband = 0.5, rate = (double)interp / (double)decim;
+    double tw, mid;
+    if (rate >= 1.0) {
+        tw = halfband - fbw;
+        mid = halfband - tw / 2.0;
+    } else {
+        tw = rate * (halfband - fbw);
+        mid = rate * halfband - tw / 2.0;
+    }
+    return sdr_firdes_low_pass(interp, interp, mid, tw, SDR_WIN_KAISER, beta, taps, cap);
+}
+
+// ------------------------------------------------------------------ tables
+static void host_nco_table(std::vector<float2>& t)
+{
+    t.resize(SDR_NCO_TAB);
+    for (int i = 0; i < SDR_NCO_TAB; ++i) {
+        t[i].x = (float)cos(2 * M_PI * i / 1024.0);
+        t[i].y = (float)sin(2 * M_PI * i / 1024.0);
+    }
+}
+
+static void host_atan_table(std::vector<float>& t)
+{
+    // gnuradio fast_atan2f table: 7-significant-digit literals of atan(i/255)
+    t.resize(258);
+    char buf[64];
+    for (int i = 0; i <= 255; ++i) {
+        snprintf(buf, sizeof buf, "%.6e", atan((double)i / 255.0));
+        t[i] = strtof(buf, nullptr);
+    }
+    t[256] = t[255];
+    t[257] = t[255];
+}
+
+static void host_pow_tables(std::vector<double>& p, std::vector<double>& l)
+{
+    p.resize(SDR_MAX_POW_TABLE);
+    l.resize(SDR_MAX_POW_TABLE);
+    p[0] = 0;
+    l[0] = 0;
+    for (int n = 1; n < SDR_MAX_POW_TABLE; ++n) {
+        p[n] = pow((double)n, -1.0 / 3.0);  // x.size ** (-1.0 / 3.0)
+        l[n] = log2((double)n);             // np.log2(x.size)
+    }
+}
+
+static unsigned long long host_nco_inc(double fc, double fs, int D)
+{
+    double f = -fc / fs * (double)D;
+    f -= floor(f);
+    if (f >= 1.0) f = 0.0;
+    return (unsigned long long)ldexp(f, 64);
+}
+
+// ------------------------------------------------------------------ helpers
+static hipError_t dev_alloc(void** p, size_t bytes)
+{
+    if (bytes == 0) bytes = 16;
+    return hipMalloc(p, bytes);
+}
+
+static int upload_taps(sdr_handle* h)
+{
+    const int n = h->ntaps;
+    const double fc = h->cfg.center_freq, fs = h->cfg.sample_rate;
+    std::vector<float> rt;
+    if (fc != 0.0) {
+        // freq_xlating_fir_filter: ctaps[k] = taps[k] * exp(j k 2 pi fc/fs)
+        h->rt_complex = true;
+        rt.resize(2 * n);
+        const double th = 2 * M_PI * fc / fs;
+        for (int k = 0; k < n; ++k) {
+            float cr, ci;
+            if (h->proto_complex) {
+                // complex prototype: full complex product in double, rounded once
+                double pr = h->proto_taps[2 * k], pi = h->proto_taps[2 * k + 1];
+                cr = (float)(pr * cos(k * th) - pi * sin(k * th));
+                ci = (float)(pr * sin(k * th) + pi * cos(k * th));
+            } else {
+                cr = (float)((double)h->proto_taps[k] * cos(k * th));
+                ci = (float)((double)h->proto_taps[k] * sin(k * th));
+            }
+            rt[2 * (n - 1 - k)] = cr;
+            rt[2 * (n - 1 - k) + 1] = ci;
+        }
+    } else if (h->proto_complex) {
+        h->rt_complex = true;
+        rt.resize(2 * n);
+        for (int k = 0; k < n; ++k) {
+            rt[2 * (n - 1 - k)] = h->proto_taps[2 * k];
+            rt[2 * (n - 1 - k) + 1] = h->proto_taps[2 * k + 1];
+        }
+    } else {
+        h->rt_complex = false;
+        rt.resize(n);
+        for (int k = 0; k < n; ++k) rt[n - 1 - k] = h->proto_taps[k];
+    }
+    if (h->d_rtaps) (void)hipFree(h->d_rtaps);
+    h->d_rtaps = nullptr;
+    HIPCHK(h, dev_alloc((void**)&h->d_rtaps, rt.size() * sizeof(float)));
+    HIPCHK(h, hipMemcpy(h->d_rtaps, rt.data(), rt.size() * sizeof(float), hipMemcpyHostToDevice));
+    h->nco_inc = (fc != 0.0) ? host_nco_inc(fc, fs, h->cfg.decim) : 0;
+    // streaming history: ntaps-1 + 2*D samples (previous output for QUAD, GR's
+    // "emit once D items are consumed" rule)
+    h->hist_len = n - 1 + 2 * h->cfg.decim;
+    if (h->hist_len > h->hist_cap) {
+        for (int i = 0; i < 2; ++i) {
+            if (h->d_hist[i]) (void)hipFree(h->d_hist[i]);
+            h->d_hist[i] = nullptr;
+            HIPCHK(h, dev_alloc((void**)&h->d_hist[i], (size_t)h->hist_len * sizeof(float2)));
+        }
+        h->hist_cap = h->hist_len;
+    }
+    for (int i = 0; i < 2; ++i)
+        HIPCHK(h, hipMemset(h->d_hist[i], 0, (size_t)h->hist_cap * sizeof(float2)));
+    return SDR_OK;
+}
+
+static double decoder_reset_limit(int dec)
+{
+    return dec == SDR_DEC_TS33C ? 1550.0 : 500.0;
+}
+
+static bool is_stream_decoder(int dec) { return dec >= SDR_DEC_TS33C && dec <= SDR_DEC_TFA_GRC; }
+
+// launch geometry of the front end: threads (= FIR outputs) per tile
+static void pick_tile(const sdr_handle* h, int& T, size_t& lds, bool& use_lds)
+{
+    const int D = h->cfg.decim, nt = h->ntaps;
+    const int cands[3] = {256, 128, 64};
+    use_lds = true;
+    for (int i = 0; i < 3; ++i) {
+        T = cands[i];
+        lds = ((size_t)(T - 1) * D + nt) * sizeof(float2);
+        if (lds <= 40 * 1024) return;
+    }
+    if (lds <= 60 * 1024) return;
+    use_lds = false;
+    T = 256;
+    lds = 0;
+}
+
+// ------------------------------------------------------------------ create
+extern "C" int sdr_version(void) { return 100; }
+
+extern "C" const char* sdr_last_error(sdr_handle* h) { return h ? h->err.c_str() : g_err.c_str(); }
+
+extern "C" int sdr_destroy(sdr_handle* h)
+{
+    if (!h) return SDR_OK;
+    (void)hipSetDevice(h->device);
+    if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
+    void* ptrs[] = {h->d_rtaps, h->d_post_rtaps, h->d_nco_tab, h->d_atan_tab, h->d_pow, h->d_log2, h->d_iq,
+                    h->d_hist[0], h->d_hist[1], h->d_bits, h->d_tap, h->d_tap2, h->d_tsum, h->d_runs,
+                    h->d_cur, h->d_st, h->d_frames};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+    delete h;
+    return SDR_OK;
+}
+
+extern "C" int sdr_create(const sdr_chain_cfg* cfg, sdr_handle** out)
+{
+    if (!cfg || !out) return fail(nullptr, SDR_E_ARG, "sdr_create: null argument");
+    *out = nullptr;
+    if (cfg->decim < 1 || cfg->keep_n < 1 || cfg->max_batch < 1 || cfg->max_samples < 1 ||
+        !(cfg->sample_rate > 0) || cfg->demod < SDR_DEMOD_NONE || cfg->demod > SDR_DEMOD_QUAD ||
+        cfg->decoder < SDR_DEC_NONE || cfg->decoder > SDR_DEC_MUMBI || cfg->post_ntaps < 0)
+        return fail(nullptr, SDR_E_ARG, "sdr_create: bad configuration");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return fail(nullptr, SDR_E_NODEVICE, "sdr_create: no HIP device (this library has no CPU path)");
+    sdr_handle* h = new sdr_handle();
+    h->cfg = *cfg;
+    if (h->cfg.max_frames < 1) h->cfg.max_frames = 16;
+    if (hipGetDevice(&h->device) != hipSuccess) {
+        delete h;
+        return fail(nullptr, SDR_E_HIP, "hipGetDevice failed");
+    }
+    int rc = SDR_OK;
+    auto body = [&]() -> int {
+        HIPCHK(h, hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+        h->stream = h->own_stream;
+        HIPCHK(h, hipEventCreate(&h->ev0));
+        HIPCHK(h, hipEventCreate(&h->ev1));
+        // tables
+        std::vector<float2> nco;
+        host_nco_table(nco);
+        HIPCHK(h, dev_alloc((void**)&h->d_nco_tab, nco.size() * sizeof(float2)));
+        HIPCHK(h, hipMemcpy(h->d_nco_tab, nco.data(), nco.size() * sizeof(float2), hipMemcpyHostToDevice));
+        std::vector<float> at;
+        host_atan_table(at);
+        HIPCHK(h, dev_alloc((void**)&h->d_atan_tab, at.size() * sizeof(float)));
+        HIPCHK(h, hipMemcpy(h->d_atan_tab, at.data(), at.size() * sizeof(float), hipMemcpyHostToDevice));
+        std::vector<double> pw, lg;
+        host_pow_tables(pw, lg);
+        HIPCHK(h, dev_alloc((void**)&h->d_pow, pw.size() * sizeof(double)));
+        HIPCHK(h, dev_alloc((void**)&h->d_log2, lg.size() * sizeof(double)));
+        HIPCHK(h, hipMemcpy(h->d_pow, pw.data(), pw.size() * sizeof(double), hipMemcpyHostToDevice));
+        HIPCHK(h, hipMemcpy(h->d_log2, lg.data(), lg.size() * sizeof(double), hipMemcpyHostToDevice));
+        // default taps = [1]
+        h->proto_taps = {1.0f};
+        h->proto_complex = false;
+        h->ntaps = 1;
+        int r = upload_taps(h);
+        if (r) return r;
+        // buffers
+        const long long B = h->cfg.max_batch;
+        const long long nout_max = (long long)(h->cfg.max_samples / h->cfg.decim) + 2;
+        const long long nb_max = nout_max / h->cfg.keep_n + 2;
+        h->dec_rate = h->cfg.decoder_rate > 0 ? h->cfg.decoder_rate
+                                              : h->cfg.sample_rate / h->cfg.decim / h->cfg.keep_n;
+        // rawBuffer may hold up to reset_limit worth of pending samples plus one call
+        long long pend = (long long)(decoder_reset_limit(h->cfg.decoder) * 1e-6 * h->dec_rate) + 64;
+        if (B > 1) pend = 0;
+        h->bits_stride = ((nb_max + pend + 63) / 64) * 64;
+        HIPCHK(h, dev_alloc((void**)&h->d_bits, (size_t)(B * h->bits_stride)));
+        HIPCHK(h, hipMemset(h->d_bits, 0, (size_t)(B * h->bits_stride)));
+        if (h->cfg.tap_demod || h->cfg.post_ntaps > 0) {
+            h->tap_stride = nout_max * (h->cfg.demod == SDR_DEMOD_NONE ? 2 : 1);
+            HIPCHK(h, dev_alloc((void**)&h->d_tap, (size_t)(B * h->tap_stride) * sizeof(float)));
+            if (h->cfg.post_ntaps > 0 && h->cfg.tap_demod)
+                HIPCHK(h, dev_alloc((void**)&h->d_tap2, (size_t)(B * h->tap_stride) * sizeof(float)));
+        }
+        h->tsum_stride = (int)(nout_max / 63 + 2);  // smallest tile emits 63 outputs (QUAD, T=64)
+        HIPCHK(h, dev_alloc((void**)&h->d_tsum, (size_t)(B * h->tsum_stride) * sizeof(TileSum)));
+        h->runs_cap = h->bits_stride;
+        HIPCHK(h, dev_alloc((void**)&h->d_runs, (size_t)(B * (h->runs_cap + 2)) * sizeof(int32_t)));
+        HIPCHK(h, dev_alloc((void**)&h->d_cur, (size_t)(B * SDR_CUR_CAP) * sizeof(double)));
+        HIPCHK(h, dev_alloc((void**)&h->d_st, (size_t)B * sizeof(DecState)));
+        HIPCHK(h, hipMemset(h->d_st, 0, (size_t)B * sizeof(DecState)));
+        {
+            DecState s0;
+            memset(&s0, 0, sizeof s0);
+            s0.thr_state = h->cfg.thr_init;
+            s0.pulse_short_limit = 775.0;
+            s0.gap_short_limit = 775.0;
+            HIPCHK(h, hipMemcpy(h->d_st, &s0, sizeof s0, hipMemcpyHostToDevice));
+        }
+        HIPCHK(h, dev_alloc((void**)&h->d_frames, (size_t)(B * h->cfg.max_frames) * sizeof(sdr_frame)));
+        h->keep_ctr = h->cfg.keep_n;
+        return SDR_OK;
+    };
+    rc = body();
+    if (rc != SDR_OK) {
+        g_err = h->err;
+        sdr_destroy(h);
+        return rc;
+    }
+    *out = h;
+    return SDR_OK;
+}
+
+extern "C" int sdr_set_taps(sdr_handle* h, const float* taps, int n, int is_complex)
+{
+    if (!h || !taps || n < 1 || n > 65536) return fail(h, SDR_E_ARG, "sdr_set_taps: bad argument");
+    (void)hipSetDevice(h->device);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->proto_taps.assign(taps, taps + (is_complex ? 2 * n : n));
+    h->proto_complex = is_complex != 0;
+    h->ntaps = n;
+    return upload_taps(h);
+}
+
+extern "C" int sdr_set_post_taps(sdr_handle* h, const float* taps, int n)
+{
+    if (!h || !taps || n < 1 || n != h->cfg.post_ntaps)
+        return fail(h, SDR_E_ARG, "sdr_set_post_taps: n must equal cfg.post_ntaps");
+    (void)hipSetDevice(h->device);
+    std::vector<float> rt(n);
+    for (int k = 0; k < n; ++k) rt[n - 1 - k] = taps[k];
+    if (!h->d_post_rtaps) HIPCHK(h, dev_alloc((void**)&h->d_post_rtaps, n * sizeof(float)));
+    HIPCHK(h, hipMemcpy(h->d_post_rtaps, rt.data(), n * sizeof(float), hipMemcpyHostToDevice));
+    h->post_taps.assign(taps, taps + n);
+    return SDR_OK;
+}
+
+extern "C" int sdr_set_stream(sdr_handle* h, void* s)
+{
+    if (!h) return SDR_E_ARG;
+    h->stream = s ? (hipStream_t)s : h->own_stream;
+    return SDR_OK;
+}
+
+extern "C" int sdr_synchronize(sdr_handle* h)
+{
+    if (!h) return SDR_E_ARG;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return SDR_OK;
+}
+
+extern "C" int sdr_timer_start(sdr_handle* h)
+{
+    if (!h) return SDR_E_ARG;
+    HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+    return SDR_OK;
+}
+extern "C" int sdr_timer_stop(sdr_handle* h)
+{
+    if (!h) return SDR_E_ARG;
+    HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+    return SDR_OK;
+}
+extern "C" int sdr_timer_elapsed_ms(sdr_handle* h, float* ms)
+{
+    if (!h || !ms) return SDR_E_ARG;
+    HIPCHK(h, hipEventSynchronize(h->ev1));
+    HIPCHK(h, hipEventElapsedTime(ms, h->ev0, h->ev1));
+    return SDR_OK;
+}
+
+// ------------------------------------------------------------------ launches
+static int ensure_iq_staging(sdr_handle* h, size_t samples)
+{
+    if (samples <= h->iq_cap) return SDR_OK;
+    if (h->d_iq) (void)hipFree(h->d_iq);
+    h->d_iq = nullptr;
+    h->iq_cap = 0;
+    HIPCHK(h, dev_alloc((void**)&h->d_iq, samples * sizeof(float2)));
+    h->iq_cap = samples;
+    return SDR_OK;
+}
+
+struct CallGeom {
+    long long nout;     // FIR/demod outputs per capture
+    long long in0;
+    long long keep_c0;
+    long long ne;       // bytes emitted per capture
+    int T, tile_out, tiles;
+    size_t lds;
+    bool use_lds;
+};
+
+static int launch_front_and_back(sdr_handle* h, const float2* x, long long stride, long long n, int ncap,
+                                 const float2* hist, int hist_len, const CallGeom& g, long long patch_off,
+                                 long long nb_total, int fresh, int use_state_thr, int run_decoder)
+{
+    const sdr_chain_cfg& c = h->cfg;
+    const bool post = c.post_ntaps > 0;
+    if (post && (int)h->post_taps.size() != c.post_ntaps)
+        return fail(h, SDR_E_ARG, "post-demod filter configured but sdr_set_post_taps not called");
+    if (g.tiles > h->tsum_stride) return fail(h, SDR_E_CAPACITY, "tile table too small");
+    if (g.nout > 0) {
+        FrontParams P;
+        memset(&P, 0, sizeof P);
+        P.x = x;
+        P.hist = hist;
+        P.stride = stride;
+        P.n = n;
+        P.nout = g.nout;
+        P.in0 = g.in0;
+        P.hist_len = hist_len;
+        P.D = c.decim;
+        P.ntaps = h->ntaps;
+        P.taps_complex = h->rt_complex;
+        P.rtaps = h->d_rtaps;
+        P.nco_inc = h->nco_inc;
+        P.nco_m0 = h->out_count;
+        P.nco_tab = (c.center_freq != 0.0) ? h->d_nco_tab : nullptr;
+        P.atan_tab = h->d_atan_tab;
+        P.demod = c.demod;
+        P.gain = post ? 1.0f : c.demod_gain;
+        P.lo = c.thr_lo;
+        P.hi = c.thr_hi;
+        P.do_slice = (c.demod != SDR_DEMOD_NONE && !post) ? 1 : 0;
+        P.keep_n = c.keep_n;
+        P.keep_c0 = g.keep_c0;
+        P.bits = h->d_bits + patch_off;
+        P.bits_stride = h->bits_stride;
+        P.tap = (c.tap_demod || post || c.demod == SDR_DEMOD_NONE) ? h->d_tap : nullptr;
+        P.tap_stride = h->tap_stride;
+        P.tsum = h->d_tsum;
+        P.tiles_per_capture = g.tiles;
+        P.tile_out = g.tile_out;
+        if (c.demod == SDR_DEMOD_NONE && !h->d_tap)
+            return fail(h, SDR_E_ARG, "demod NONE needs cfg.tap_demod (complex output buffer)");
+        dim3 grid(g.tiles, ncap), block(g.T);
+        if (g.use_lds)
+            hipLaunchKernelGGL(k_frontend<true>, grid, block, g.lds, h->stream, P);
+        else
+            hipLaunchKernelGGL(k_frontend<false>, grid, block, 0, h->stream, P);
+        HIPCHK(h, hipGetLastError());
+        if (post) {
+            PostParams Q;
+            memset(&Q, 0, sizeof Q);
+            Q.v = h->d_tap;
+            Q.v_stride = h->tap_stride;
+            Q.nout = g.nout;
+            Q.ntaps = c.post_ntaps;
+            Q.rtaps = h->d_post_rtaps;
+            Q.gain = c.demod_gain;
+            Q.lo = c.thr_lo;
+            Q.hi = c.thr_hi;
+            Q.keep_n = c.keep_n;
+            Q.keep_c0 = g.keep_c0;
+            Q.bits = h->d_bits + patch_off;
+            Q.bits_stride = h->bits_stride;
+            Q.tap = h->d_tap2;
+            Q.tap_stride = h->tap_stride;
+            Q.tsum = h->d_tsum;
+            Q.tiles_per_capture = g.tiles;
+            Q.tile_out = g.tile_out;
+            size_t lds = (size_t)(g.T + c.post_ntaps) * sizeof(float);
+            hipLaunchKernelGGL(k_post_fir_slice, grid, block, lds, h->stream, Q);
+            HIPCHK(h, hipGetLastError());
+        }
+    }
+    if (c.demod == SDR_DEMOD_NONE) return SDR_OK;
+    BackParams Bp;
+    memset(&Bp, 0, sizeof Bp);
+    Bp.bits = h->d_bits;
+    Bp.bits_stride = h->bits_stride;
+    Bp.nb = nb_total;
+    Bp.tsum = g.nout > 0 ? h->d_tsum : nullptr;
+    Bp.tiles_per_capture = g.tiles;
+    Bp.tile_out = g.tile_out;
+    Bp.nout = g.nout;
+    Bp.keep_n = c.keep_n;
+    Bp.keep_c0 = g.keep_c0;
+    Bp.patch_off = patch_off;
+    Bp.thr_init = c.thr_init;
+    Bp.use_state_thr = use_state_thr;
+    Bp.run_decoder = run_decoder;
+    Bp.decoder = c.decoder;
+    Bp.fresh = fresh;
+    Bp.dec_rate = h->dec_rate;
+    Bp.runs = h->d_runs;
+    Bp.runs_cap = h->runs_cap;
+    Bp.cur = h->d_cur;
+    Bp.st = h->d_st;
+    Bp.frames = h->d_frames;
+    Bp.max_frames = c.max_frames;
+    Bp.pow_m13 = h->d_pow;
+    Bp.log2n = h->d_log2;
+    hipLaunchKernelGGL(k_backend, dim3(ncap), dim3(BK_THREADS), 0, h->stream, Bp);
+    HIPCHK(h, hipGetLastError());
+    return SDR_OK;
+}
+
+static void fill_geom(const sdr_handle* h, long long nout, long long in0, long long keep_c0, CallGeom& g)
+{
+    g.nout = nout;
+    g.in0 = in0;
+    g.keep_c0 = keep_c0;
+    const long long kn = h->cfg.keep_n;
+    g.ne = nout > keep_c0 ? (nout - keep_c0 + kn - 1) / kn : 0;
+    if (h->cfg.post_ntaps > 0) {
+        // the post-filter kernel uses the same tiling; one output per thread
+        g.T = 256;
+        g.lds = 0;
+        g.use_lds = true;
+        int T;
+        size_t lds;
+        bool ul;
+        pick_tile(h, T, lds, ul);
+        g.T = T;
+        g.lds = lds;
+        g.use_lds = ul;
+    } else
+        pick_tile(h, g.T, g.lds, g.use_lds);
+    g.tile_out = g.T - (h->cfg.demod == SDR_DEMOD_QUAD ? 1 : 0);
+    g.tiles = (int)((nout + g.tile_out - 1) / g.tile_out);
+}
+
+static int finish_out(sdr_handle* h, sdr_out* out, unsigned long long n_in, long long nbits)
+{
+    if (!out) return SDR_OK;
+    out->n_in = n_in;
+    out->n_bits = (uint64_t)nbits;
+    out->n_frames = 0;
+    out->overflow = 0;
+    out->pad_ = 0;
+    return SDR_OK;
+}
+
+extern "C" int sdr_batch_process(sdr_handle* h, const void* iq, size_t n, size_t stride, int ncap,
+                                 int is_dev, sdr_out* out)
+{
+    if (!h || !iq || ncap < 1) return fail(h, SDR_E_ARG, "sdr_batch_process: bad argument");
+    if (ncap > h->cfg.max_batch || n > h->cfg.max_samples)
+        return fail(h, SDR_E_CAPACITY, "sdr_batch_process: batch larger than the handle was created for");
+    if (stride < n) return fail(h, SDR_E_ARG, "sdr_batch_process: stride < n_per_capture");
+    (void)hipSetDevice(h->device);
+    const float2* x = (const float2*)iq;
+    if (!is_dev) {
+        int r = ensure_iq_staging(h, (size_t)ncap * stride);
+        if (r) return r;
+        HIPCHK(h, hipMemcpyAsync(h->d_iq, iq, (size_t)((ncap - 1) * stride + n) * sizeof(float2),
+                                 hipMemcpyHostToDevice, h->stream));
+        x = h->d_iq;
+    }
+    const sdr_chain_cfg& c = h->cfg;
+    CallGeom g;
+    // gr::sync_decimator: a finite capture of n items yields n/D outputs
+    fill_geom(h, (long long)(n / c.decim), 0, c.keep_n - 1, g);
+    unsigned long long saved = h->out_count;
+    h->out_count = 0;  // every capture starts at NCO phase 0
+    int run = 1;
+    if (is_stream_decoder(c.decoder))
+        run = ((double)g.ne * 1e6 / h->dec_rate > decoder_reset_limit(c.decoder)) ? 1 : 0;
+    int r = launch_front_and_back(h, x, (long long)stride, (long long)n, ncap, nullptr, 0, g, 0, g.ne, 1, 0, run);
+    h->out_count = saved;
+    if (r) return r;
+    h->last_ncap = ncap;
+    h->last_nb = g.ne;
+    h->last_nout = g.nout;
+    h->last_bits_off = 0;
+    return finish_out(h, out, (unsigned long long)n * ncap, g.ne);
+}
+
+static int stream_decode_step(sdr_handle* h, const CallGeom& g, const float2* x, long long n,
+                              bool have_iq, sdr_out* out, unsigned long long n_in)
+{
+    const sdr_chain_cfg& c = h->cfg;
+    const long long total = h->raw_n + g.ne;
+    if (total > h->bits_stride) return fail(h, SDR_E_CAPACITY, "rawBuffer capacity exceeded");
+    int run = 0;
+    if (is_stream_decoder(c.decoder))
+        run = ((double)total * 1e6 / h->dec_rate > decoder_reset_limit(c.decoder)) ? 1 : 0;
+    else if (c.decoder != SDR_DEC_NONE)
+        run = 1;
+    const long long off = (c.decoder == SDR_DEC_NONE || !is_stream_decoder(c.decoder)) ? 0 : h->raw_n;
+    const long long nb_total = (off == 0) ? g.ne : total;
+    int r;
+    if (have_iq)
+        r = launch_front_and_back(h, x, 0, n, 1, h->d_hist[h->hist_sel], h->hist_len, g, off, nb_total, 0, 1, run);
+    else {
+        CallGeom g0 = g;
+        g0.nout = 0;
+        g0.tiles = 0;
+        r = launch_front_and_back(h, nullptr, 0, 0, 1, nullptr, 0, g0, off, nb_total, 0, 1, run);
+    }
+    if (r) return r;
+    h->last_ncap = 1;
+    h->last_nb = g.ne;
+    h->last_nout = g.nout;
+    h->last_bits_off = off;
+    if (is_stream_decoder(c.decoder)) h->raw_n = run ? 0 : total;
+    return finish_out(h, out, n_in, g.ne);
+}
+
+extern "C" int sdr_process_iq(sdr_handle* h, const void* iq, size_t n, int is_dev, sdr_out* out)
+{
+    if (!h || (!iq && n)) return fail(h, SDR_E_ARG, "sdr_process_iq: bad argument");
+    if (n > h->cfg.max_samples) return fail(h, SDR_E_CAPACITY, "sdr_process_iq: chunk larger than max_samples");
+    if (h->cfg.post_ntaps > 0)
+        return fail(h, SDR_E_ARG, "post-demod filter chains are batch-only in this version");
+    (void)hipSetDevice(h->device);
+    const sdr_chain_cfg& c = h->cfg;
+    const float2* x = (const float2*)iq;
+    if (!is_dev && n) {
+        int r = ensure_iq_staging(h, n);
+        if (r) return r;
+        HIPCHK(h, hipMemcpyAsync(h->d_iq, iq, n * sizeof(float2), hipMemcpyHostToDevice, h->stream));
+        x = h->d_iq;
+    }
+    const unsigned long long A = h->in_count;
+    const long long D = c.decim;
+    const unsigned long long m_end = (A + n) / D;  // outputs emitted once D items are consumed
+    CallGeom g;
+    const long long nout = (long long)(m_end - h->out_count);
+    const long long in0 = (long long)(h->out_count * D) - (long long)A;
+    fill_geom(h, nout, in0, h->keep_ctr - 1, g);
+    int r = stream_decode_step(h, g, x, (long long)n, true, out, n);
+    if (r) return r;
+    // history for the next call: last hist_len samples of (hist ++ x)
+    if (n) {
+        const int H = h->hist_len;
+        float2* cur = h->d_hist[h->hist_sel];
+        float2* nxt = h->d_hist[h->hist_sel ^ 1];
+        if ((long long)n >= H)
+            HIPCHK(h, hipMemcpyAsync(nxt, x + (n - H), (size_t)H * sizeof(float2), hipMemcpyDeviceToDevice, h->stream));
+        else {
+            HIPCHK(h, hipMemcpyAsync(nxt, cur + n, (size_t)(H - n) * sizeof(float2), hipMemcpyDeviceToDevice, h->stream));
+            HIPCHK(h, hipMemcpyAsync(nxt + (H - n), x, n * sizeof(float2), hipMemcpyDeviceToDevice, h->stream));
+        }
+        h->hist_sel ^= 1;
+    }
+    // counters
+    h->in_count = A + n;
+    h->out_count = m_end;
+    if (g.ne == 0)
+        h->keep_ctr -= nout;
+    else {
+        long long last = g.keep_c0 + (g.ne - 1) * c.keep_n;
+        h->keep_ctr = c.keep_n - (nout - 1 - last);
+    }
+    return SDR_OK;
+}
+
+extern "C" int sdr_process_bits(sdr_handle* h, const int8_t* bits, size_t n, int is_dev, sdr_out* out)
+{
+    if (!h || (!bits && n)) return fail(h, SDR_E_ARG, "sdr_process_bits: bad argument");
+    if (h->cfg.decoder == SDR_DEC_NONE) return fail(h, SDR_E_ARG, "sdr_process_bits: no decoder configured");
+    (void)hipSetDevice(h->device);
+    const long long off = is_stream_decoder(h->cfg.decoder) ? h->raw_n : 0;
+    if (off + (long long)n > h->bits_stride) return fail(h, SDR_E_CAPACITY, "sdr_process_bits: chunk too large");
+    if (n)
+        HIPCHK(h, hipMemcpyAsync(h->d_bits + off, bits, n, is_dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
+                                 h->stream));
+    CallGeom g;
+    memset(&g, 0, sizeof g);
+    g.ne = (long long)n;
+    g.T = 256;
+    g.tile_out = 256;
+    return stream_decode_step(h, g, nullptr, 0, false, out, 0);
+}
+
+// ------------------------------------------------------------------ results
+extern "C" int sdr_fetch_frames(sdr_handle* h, sdr_frame* outp, size_t cap, size_t* n)
+{
+    if (!h || !n) return fail(h, SDR_E_ARG, "sdr_fetch_frames: bad argument");
+    (void)hipSetDevice(h->device);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const int B = h->last_ncap;
+    *n = 0;
+    if (B == 0) return SDR_OK;
+    std::vector<DecState> st(B);
+    HIPCHK(h, hipMemcpy(st.data(), h->d_st, (size_t)B * sizeof(DecState), hipMemcpyDeviceToHost));
+    size_t total = 0;
+    int overflow = 0;
+    for (int i = 0; i < B; ++i) {
+        total += st[i].n_frames;
+        overflow |= st[i].overflow;
+    }
+    *n = total;
+    if (outp && cap) {
+        std::vector<sdr_frame> all((size_t)B * h->cfg.max_frames);
+        HIPCHK(h, hipMemcpy(all.data(), h->d_frames, all.size() * sizeof(sdr_frame), hipMemcpyDeviceToHost));
+        size_t k = 0;
+        for (int i = 0; i < B && k < cap; ++i)
+            for (int j = 0; j < st[i].n_frames && k < cap; ++j) outp[k++] = all[(size_t)i * h->cfg.max_frames + j];
+    }
+    if (overflow) return fail(h, SDR_E_OVERFLOW, "device table overflow (runs/frames/symbols), code " + std::to_string(overflow));
+    return SDR_OK;
+}
+
+extern "C" int sdr_fetch_bits(sdr_handle* h, int8_t* outp, size_t cap, size_t* n)
+{
+    if (!h || !n) return fail(h, SDR_E_ARG, "sdr_fetch_bits: bad argument");
+    (void)hipSetDevice(h->device);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const size_t total = (size_t)h->last_ncap * (size_t)h->last_nb;
+    *n = total;
+    if (!outp || cap < total || total == 0) return SDR_OK;
+    HIPCHK(h, hipMemcpy2D(outp, (size_t)h->last_nb, h->d_bits + h->last_bits_off, (size_t)h->bits_stride,
+                          (size_t)h->last_nb, (size_t)h->last_ncap, hipMemcpyDeviceToHost));
+    return SDR_OK;
+}
+
+extern "C" int sdr_fetch_demod(sdr_handle* h, float* outp, size_t cap, size_t* n)
+{
+    if (!h || !n) return fail(h, SDR_E_ARG, "sdr_fetch_demod: bad argument");
+    if (!h->d_tap) return fail(h, SDR_E_ARG, "sdr_fetch_demod: handle created without tap_demod");
+    (void)hipSetDevice(h->device);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const size_t w = (size_t)h->last_nout * (h->cfg.demod == SDR_DEMOD_NONE ? 2 : 1);
+    const size_t total = (size_t)h->last_ncap * w;
+    *n = total;
+    if (!outp || cap < total || total == 0) return SDR_OK;
+    const float* src = (h->cfg.post_ntaps > 0 && h->d_tap2) ? h->d_tap2 : h->d_tap;
+    HIPCHK(h, hipMemcpy2D(outp, w * sizeof(float), src, (size_t)h->tap_stride * sizeof(float), w * sizeof(float),
+                          (size_t)h->last_ncap, hipMemcpyDeviceToHost));
+    return SDR_OK;
+}
+
+extern "C" int sdr_decoder_state(sdr_handle* h, int32_t state[4])
+{
+    if (!h || !state) return SDR_E_ARG;
+    (void)hipSetDevice(h->device);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    DecState s;
+    HIPCHK(h, hipMemcpy(&s, h->d_st, sizeof s, hipMemcpyDeviceToHost));
+    state[0] = s.state;
+    state[1] = s.n_cur;
+    state[2] = s.prev_type;
+    state[3] = s.chunk_id;
+    return SDR_OK;
+}
+
+#include "fm_host.h"
+#include "selftest.h"

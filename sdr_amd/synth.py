@@ -308,6 +308,18 @@ def ts33c_capture(n, fs, seed, f_off=0.0, n_frames=3, **fields):
 
 
 def random_ts33c_fields(rng):
+    """Random sensor fields.  The last filler byte gets even bit-parity: its
+    parity bit is then 1 and rides on the frame's final short pulse, the only
+    tail `ts33c_symbols` can represent (README frame ends the same way)."""
+    f = dict(_random_ts33c_fields(rng))
+    fl = list(f["filler"])
+    if bin(fl[4]).count("1") % 2:
+        fl[4] ^= 1
+    f["filler"] = tuple(fl)
+    return f
+
+
+def _random_ts33c_fields(rng):
     return dict(channel=int(rng.integers(1, 4)), rolling_code=int(rng.integers(0, 16)),
                 temp_tenths=int(rng.integers(-399, 600)), humidity=int(rng.integers(0, 100)),
                 battery_ok=bool(rng.integers(0, 2)),
