@@ -187,6 +187,21 @@ SDR_API int sdr_timer_start(sdr_handle* h);
 SDR_API int sdr_timer_stop(sdr_handle* h);
 SDR_API int sdr_timer_elapsed_ms(sdr_handle* h, float* ms);
 
+/* Per-launch kernel timing: when enabled, every call brackets its front-end
+ * (filter+demod+slice) and back-end (run-length+decode) launches with HIP
+ * events on the handle's stream (ring of 256 calls, no host sync).
+ * sdr_profile_read synchronises and returns the last n<=cap durations. */
+SDR_API int sdr_profile_enable(sdr_handle* h, int on);
+SDR_API int sdr_profile_read(sdr_handle* h, float* front_ms, float* back_ms, int cap, int* n);
+
+/* Device-side export for a multi-GPU frame gather: copies the last batch's
+ * frame records (n_captures*max_frames sdr_frame, unused slots zeroed) and
+ * per-capture frame counts (n_captures int32) into caller-owned DEVICE buffers
+ * on the handle's stream, ready for an RCCL all_gather.  No counterpart in the
+ * reference (it has no multi-device path); serves BASELINE.json configs[3]. */
+SDR_API int sdr_export_frames(sdr_handle* h, void* frames_dev, size_t frames_bytes, void* counts_dev,
+                              size_t counts_bytes);
+
 SDR_API int sdr_version(void);
 
 #ifdef __cplusplus

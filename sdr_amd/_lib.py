@@ -101,6 +101,7 @@ EXPORTS = [
     "sdr_set_post_taps", "sdr_set_stream", "sdr_synchronize", "sdr_last_error", "sdr_process_iq",
     "sdr_process_bits", "sdr_batch_process", "sdr_fetch_frames", "sdr_fetch_bits", "sdr_fetch_demod",
     "sdr_decoder_state", "sdr_timer_start", "sdr_timer_stop", "sdr_timer_elapsed_ms", "sdr_version",
+    "sdr_profile_enable", "sdr_profile_read", "sdr_export_frames",
 ]
 
 _lib = None
@@ -155,6 +156,12 @@ def load():
     L.sdr_timer_elapsed_ms.restype = C.c_int
     L.sdr_timer_elapsed_ms.argtypes = [H, C.POINTER(C.c_float)]
     L.sdr_version.restype = C.c_int
+    L.sdr_profile_enable.restype = C.c_int
+    L.sdr_profile_enable.argtypes = [H, C.c_int]
+    L.sdr_profile_read.restype = C.c_int
+    L.sdr_profile_read.argtypes = [H, fp, fp, C.c_int, C.POINTER(C.c_int)]
+    L.sdr_export_frames.restype = C.c_int
+    L.sdr_export_frames.argtypes = [H, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
     # host-compiled test hooks (csrc/selftest.h); not used by the product path
     L.sdr_selftest_hist_mid_edge.restype = C.c_int
     L.sdr_selftest_hist_mid_edge.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double)]

@@ -174,6 +174,24 @@ class Chain(object):
         _lib.check(self._h, self._L.sdr_decoder_state(self._h, C.byref(st)))
         return list(st)
 
+    def profile_enable(self, on=True):
+        _lib.check(self._h, self._L.sdr_profile_enable(self._h, int(on)))
+
+    def profile_read(self):
+        """-> (front_ms[], back_ms[]) HIP-event durations of the last <=256 calls."""
+        f = (C.c_float * 256)()
+        b = (C.c_float * 256)()
+        n = C.c_int()
+        _lib.check(self._h, self._L.sdr_profile_read(self._h, f, b, 256, C.byref(n)))
+        return list(f[:n.value]), list(b[:n.value])
+
+    def export_frames(self, frames_tensor, counts_tensor):
+        """Copy the last batch's frame records / per-capture counts into torch
+        tensors on this GPU (uint8 [ncap*max_frames*96], int32 [ncap])."""
+        _lib.check(self._h, self._L.sdr_export_frames(
+            self._h, C.c_void_p(frames_tensor.data_ptr()), frames_tensor.numel() * frames_tensor.element_size(),
+            C.c_void_p(counts_tensor.data_ptr()), counts_tensor.numel() * counts_tensor.element_size()))
+
     # -- timing on the stream the kernels run on
     def timer_start(self):
         _lib.check(self._h, self._L.sdr_timer_start(self._h))

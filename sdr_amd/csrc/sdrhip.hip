@@ -65,7 +65,12 @@ struct sdr_handle {
     long long last_nb = 0, last_nout = 0, last_bits_off = 0;
     double dec_rate = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // per-launch profiling ring
+    bool profile = false;
+    std::vector<hipEvent_t> pev;   // 3 events per slot: front start, front end/back start, back end
+    unsigned long long pcount = 0;
 };
+#define SDR_PROF_RING 256
 
 static thread_local std::string g_err;
 
@@ -331,6 +336,7 @@ extern "C" int sdr_destroy(sdr_handle* h)
                     h->d_cur, h->d_st, h->d_frames};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
+    for (hipEvent_t e : h->pev) (void)hipEventDestroy(e);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -554,6 +560,7 @@ static int launch_front_and_back(sdr_handle* h, const float2* x, long long strid
         if (c.demod == SDR_DEMOD_NONE && !h->d_tap)
             return fail(h, SDR_E_ARG, "demod NONE needs cfg.tap_demod (complex output buffer)");
         dim3 grid(g.tiles, ncap), block(g.T);
+        if (h->profile) HIPCHK(h, hipEventRecord(h->pev[3 * (h->pcount % SDR_PROF_RING)], h->stream));
         if (g.use_lds)
             hipLaunchKernelGGL(k_frontend<true>, grid, block, g.lds, h->stream, P);
         else
@@ -584,7 +591,17 @@ static int launch_front_and_back(sdr_handle* h, const float2* x, long long strid
             HIPCHK(h, hipGetLastError());
         }
     }
-    if (c.demod == SDR_DEMOD_NONE) return SDR_OK;
+    if (h->profile) {
+        if (g.nout <= 0) HIPCHK(h, hipEventRecord(h->pev[3 * (h->pcount % SDR_PROF_RING)], h->stream));
+        HIPCHK(h, hipEventRecord(h->pev[3 * (h->pcount % SDR_PROF_RING) + 1], h->stream));
+    }
+    if (c.demod == SDR_DEMOD_NONE) {
+        if (h->profile) {
+            HIPCHK(h, hipEventRecord(h->pev[3 * (h->pcount % SDR_PROF_RING) + 2], h->stream));
+            h->pcount++;
+        }
+        return SDR_OK;
+    }
     BackParams Bp;
     memset(&Bp, 0, sizeof Bp);
     Bp.bits = h->d_bits;
@@ -613,6 +630,10 @@ static int launch_front_and_back(sdr_handle* h, const float2* x, long long strid
     Bp.log2n = h->d_log2;
     hipLaunchKernelGGL(k_backend, dim3(ncap), dim3(BK_THREADS), 0, h->stream, Bp);
     HIPCHK(h, hipGetLastError());
+    if (h->profile) {
+        HIPCHK(h, hipEventRecord(h->pev[3 * (h->pcount % SDR_PROF_RING) + 2], h->stream));
+        h->pcount++;
+    }
     return SDR_OK;
 }
 
@@ -854,6 +875,72 @@ extern "C" int sdr_decoder_state(sdr_handle* h, int32_t state[4])
     state[1] = s.n_cur;
     state[2] = s.prev_type;
     state[3] = s.chunk_id;
+    return SDR_OK;
+}
+
+extern "C" int sdr_profile_enable(sdr_handle* h, int on)
+{
+    if (!h) return SDR_E_ARG;
+    (void)hipSetDevice(h->device);
+    if (on && h->pev.empty()) {
+        h->pev.resize(3 * SDR_PROF_RING);
+        for (auto& e : h->pev) HIPCHK(h, hipEventCreate(&e));
+    }
+    h->profile = on != 0;
+    h->pcount = 0;
+    return SDR_OK;
+}
+
+extern "C" int sdr_profile_read(sdr_handle* h, float* front_ms, float* back_ms, int cap, int* n)
+{
+    if (!h || !n) return SDR_E_ARG;
+    (void)hipSetDevice(h->device);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    unsigned long long have = h->pcount < SDR_PROF_RING ? h->pcount : SDR_PROF_RING;
+    if ((unsigned long long)cap < have) have = cap;
+    *n = (int)have;
+    for (unsigned long long i = 0; i < have; ++i) {
+        unsigned long long slot = (h->pcount - have + i) % SDR_PROF_RING;
+        float a = 0, b = 0;
+        HIPCHK(h, hipEventElapsedTime(&a, h->pev[3 * slot], h->pev[3 * slot + 1]));
+        HIPCHK(h, hipEventElapsedTime(&b, h->pev[3 * slot + 1], h->pev[3 * slot + 2]));
+        if (front_ms) front_ms[i] = a;
+        if (back_ms) back_ms[i] = b;
+    }
+    return SDR_OK;
+}
+
+__global__ void k_export_frames(const sdr_frame* __restrict__ src, const DecState* __restrict__ st, int ncap,
+                                int max_frames, sdr_frame* __restrict__ dst, int32_t* __restrict__ counts)
+{
+    // one sdr_frame = 24 dwords; thread per dword, zero the unused slots
+    const int words = sizeof(sdr_frame) / 4;
+    long long total = (long long)ncap * max_frames * words;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        long long rec = i / words;
+        int cap = (int)(rec / max_frames), k = (int)(rec % max_frames);
+        unsigned int v = (k < st[cap].n_frames) ? reinterpret_cast<const unsigned int*>(src)[i] : 0u;
+        reinterpret_cast<unsigned int*>(dst)[i] = v;
+        if (i < ncap) counts[i] = st[i].n_frames;
+    }
+}
+
+extern "C" int sdr_export_frames(sdr_handle* h, void* frames_dev, size_t frames_bytes, void* counts_dev,
+                                 size_t counts_bytes)
+{
+    if (!h || !frames_dev || !counts_dev) return fail(h, SDR_E_ARG, "sdr_export_frames: null buffer");
+    const int B = h->last_ncap;
+    if (frames_bytes < (size_t)B * h->cfg.max_frames * sizeof(sdr_frame) || counts_bytes < (size_t)B * 4)
+        return fail(h, SDR_E_CAPACITY, "sdr_export_frames: destination too small");
+    if (B == 0) return SDR_OK;
+    (void)hipSetDevice(h->device);
+    long long total = (long long)B * h->cfg.max_frames * (sizeof(sdr_frame) / 4);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_export_frames, dim3(blocks), dim3(256), 0, h->stream, h->d_frames, h->d_st, B,
+                       h->cfg.max_frames, (sdr_frame*)frames_dev, (int32_t*)counts_dev);
+    HIPCHK(h, hipGetLastError());
     return SDR_OK;
 }
 
