@@ -489,9 +489,22 @@ SDR_HD inline void rule_mumbi(const EdgeCtx& e, const BackParams& P, DecState* s
 }
 
 // ---- the stream decoder front end (TS33C/stream_decoder.py:39-110,204-217) ----
-SDR_HD inline void stream_decode(const BackParams& P, int cap, const int32_t* pos, long long R,
-                                     int first_level, int last_level, bool any_one, double* cur,
-                                     DecState* st, double* cur_lds, double* scratch)
+// W(k) = k-th run width in us; `cur` = currentSymbols working array (LDS on the
+// device), `st` = a private copy of the persistent state.
+struct WidthsArray {
+    const double* w;
+    SDR_HD double operator()(long long k) const { return w[k]; }
+};
+struct WidthsFromPos {
+    const int32_t* pos;
+    double rate;
+    SDR_HD double operator()(long long k) const { return run_width(pos, k, rate); }
+};
+
+template <class WF>
+SDR_HD inline void stream_decode(const BackParams& P, int cap, WF W, const int32_t* pos, long long R,
+                                 int first_level, int last_level, bool any_one, double* cur,
+                                 DecState* st, double* scratch)
 {
     const bool ts33c = (P.decoder == SDR_DEC_TS33C);
     const double reset_limit = ts33c ? 1550.0 : 500.0;
@@ -505,7 +518,7 @@ SDR_HD inline void stream_decode(const BackParams& P, int cap, const int32_t* po
     // pieces end after every width > reset_limit (:77)
     long long n_over = 0;
     for (long long k = 0; k < R; ++k)
-        if (run_width(pos, k, P.dec_rate) > reset_limit) ++n_over;
+        if (W(k) > reset_limit) ++n_over;
     const long long npieces = n_over + 1;
     const bool size_is_1 = (npieces == 1 && R == 1);
     if (npieces > 1) st->state = 1;
@@ -515,7 +528,7 @@ SDR_HD inline void stream_decode(const BackParams& P, int cap, const int32_t* po
         if (pc == npieces - 1)
             b = R;
         else {
-            while (run_width(pos, b, P.dec_rate) <= reset_limit) ++b;
+            while (W(b) <= reset_limit) ++b;
             ++b;  // the over-limit width closes the piece
         }
         long long s = a;
@@ -523,12 +536,12 @@ SDR_HD inline void stream_decode(const BackParams& P, int cap, const int32_t* po
         if (s < b) {
             st->state = 1;
             if (st->n_cur > 0 && st->prev_type == cur_type) {  // (:98-100)
-                cur[st->n_cur - 1] += run_width(pos, s, P.dec_rate);
+                cur[st->n_cur - 1] += W(s);
                 ++s;
             }
             for (long long k = s; k < b; ++k) {
                 if (st->n_cur < SDR_CUR_CAP)
-                    cur[st->n_cur++] = run_width(pos, k, P.dec_rate);
+                    cur[st->n_cur++] = W(k);
                 else
                     st->overflow |= 4;
             }
@@ -539,12 +552,10 @@ SDR_HD inline void stream_decode(const BackParams& P, int cap, const int32_t* po
             if (st->n_cur > 1 && cur[st->n_cur - 1] > reset_limit) {  // (:110)
                 sdr_frame* f = next_frame(P, st, cap, pos[b]);
                 if (f) {
-                    int n = st->n_cur;
-                    for (int i = 0; i < n; ++i) cur_lds[i] = cur[i];
                     if (ts33c)
-                        decode_ts33c(cur_lds, n, reset_limit, scratch, st, P, f);
+                        decode_ts33c(cur, st->n_cur, reset_limit, scratch, st, P, f);
                     else
-                        decode_tfa(cur_lds, n, scratch, P.decoder == SDR_DEC_TFA_GRC, f);
+                        decode_tfa(cur, st->n_cur, scratch, P.decoder == SDR_DEC_TFA_GRC, f);
                 }
                 st->n_cur = 0;  // done with this packet (:204)
             }
@@ -556,6 +567,10 @@ SDR_HD inline void stream_decode(const BackParams& P, int cap, const int32_t* po
     st->prev_type = last_level;  // rawBuffer[-2] (:212)
 }
 
+#if defined(__HIPCC__)
+#include "backend_wave.h"
+#endif
+
 __global__ void __launch_bounds__(BK_THREADS) k_backend(BackParams P)
 {
     __shared__ int s_cnt[BK_THREADS];
@@ -563,6 +578,9 @@ __global__ void __launch_bounds__(BK_THREADS) k_backend(BackParams P)
     __shared__ int s_last[BK_THREADS];
     __shared__ double s_cur[SDR_CUR_CAP];
     __shared__ double s_scratch[SDR_CUR_CAP];
+    __shared__ double s_w[SDR_CUR_CAP];
+    __shared__ unsigned int s_words[64];
+    __shared__ unsigned char s_par[256];
     __shared__ unsigned char s_bits[512];
     __shared__ long long s_R;
 
@@ -621,9 +639,11 @@ __global__ void __launch_bounds__(BK_THREADS) k_backend(BackParams P)
             if (fe >= 0) carry = ts[i].last_state;
         }
         __syncthreads();
-        // thread that owns the last tile publishes the carry-out
-        if (t0 < nt && t1 == nt) st->thr_state = carry;
-        if (nt == 0 && tid == 0) st->thr_state = carry;
+        // the thread that owns the last tile hands the carry-out to thread 0
+        // through LDS; thread 0 is the only writer of *st
+        if ((t0 < nt && t1 == nt) || (nt == 0 && tid == 0)) s_cnt[0] = carry;
+        __syncthreads();
+        if (tid == 0) st->thr_state = s_cnt[0];
     }
     if (!P.run_decoder || P.decoder == SDR_DEC_NONE) return;
     __syncthreads();
@@ -674,24 +694,42 @@ __global__ void __launch_bounds__(BK_THREADS) k_backend(BackParams P)
             prev = b;
         }
     }
+    if (tid == 0) pos[R] = (int32_t)nb;
     __syncthreads();
-    if (tid != 0) return;
-    pos[R] = (int32_t)nb;
+    // run widths and the pending symbols into LDS (all threads), then one
+    // thread walks them: every access of the sequential part is an LDS access
+    const bool w_in_lds = R <= SDR_CUR_CAP;
+    if (w_in_lds)
+        for (long long k = tid; k < R; k += BK_THREADS) s_w[k] = run_width(pos, k, P.dec_rate);
+    double* gcur = P.cur + (long long)cap * SDR_CUR_CAP;
+    {
+        const int npend = st->n_cur;
+        for (int k = tid; k < npend && k < SDR_CUR_CAP; k += BK_THREADS) s_cur[k] = gcur[k];
+    }
+    __syncthreads();
+    if (tid >= 64) return;
 
-    // ---- phase 2: decode (one thread; a few hundred symbols) -----------------
+    // ---- phase 2: decode on wavefront 0 (backend_wave.h) ---------------------
     if (nb == 0) return;
+    DecState ls = *st;
     const int first_level = bits[0] != 0, last_level = bits[nb - 1] != 0;
     const bool any_one = first_level || R > 1;
     if (P.decoder <= SDR_DEC_TFA_GRC) {
-        stream_decode(P, cap, pos, R, first_level, last_level, any_one,
-                      P.cur + (long long)cap * SDR_CUR_CAP, st, s_cur, s_scratch);
-    } else {
+        WaveLds L{s_cur, s_scratch, s_words, s_par};
+        if (w_in_lds)
+            wave_stream_decode(P, cap, WidthsArray{s_w}, pos, R, first_level, last_level, any_one, L, &ls);
+        else
+            wave_stream_decode(P, cap, WidthsFromPos{pos, P.dec_rate}, pos, R, first_level, last_level, any_one, L,
+                               &ls);
+        for (int k = tid; k < ls.n_cur; k += 64) gcur[k] = s_cur[k];
+    } else if (tid == 0) {
         EdgeCtx e{pos, R, nb, first_level, (long long)P.dec_rate};
         if (P.decoder == SDR_DEC_SOMFY)
-            rule_somfy(e, P, st, cap, s_bits);
+            rule_somfy(e, P, &ls, cap, s_bits);
         else if (P.decoder == SDR_DEC_BERNER)
-            rule_berner(e, P, st, cap, s_bits);
+            rule_berner(e, P, &ls, cap, s_bits);
         else if (P.decoder == SDR_DEC_MUMBI)
-            rule_mumbi(e, P, st, cap, s_bits);
+            rule_mumbi(e, P, &ls, cap, s_bits);
     }
+    if (tid == 0) *st = ls;
 }

@@ -1,0 +1,332 @@
+// Wave-parallel form of the stream decoder for the device: the same steps as
+// the sequential stream_decode / decode_ts33c / decode_tfa in backend_kernels.h
+// (which remain the host-testable statement of the algorithm), executed by the
+// 64 lanes of one wavefront on LDS-resident symbols:
+//   * piece boundaries and packet-complete tests by ballot,
+//   * np.histogram "auto" order statistics by an O(n) per-lane rank sort,
+//   * symbol -> bit classification, short-gap removal and TFA run expansion by
+//     ballot / shuffle prefix sums, bytes assembled with LDS atomic OR.
+// Every function is called by all 64 lanes with wave-uniform arguments.
+#pragma once
+#include "backend_kernels.h"
+
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ unsigned long long lanemask_lt()
+{
+    return (1ull << (threadIdx.x & 63)) - 1ull;
+}
+
+struct WaveLds {
+    double* cur;            // currentSymbols [SDR_CUR_CAP]
+    double* scratch;        // [SDR_CUR_CAP]
+    unsigned int* words;    // [64]  packed data bits
+    unsigned char* par;     // [256] parity bits
+};
+
+// dst[rank] = value for every valid element; returns the number of valid ones.
+template <class V, class OK>
+__device__ inline int wave_rank_sort(V val, OK ok, int n, double* dst)
+{
+    const int lane = threadIdx.x & 63;
+    int total = 0;
+    for (int base = 0; base < n; base += 64) {
+        const int i = base + lane;
+        const bool mine = i < n && ok(i);
+        const double v = mine ? val(i) : 0.0;
+        int rank = 0;
+        for (int j = 0; j < n; ++j) {
+            const double u = val(j);
+            const bool vj = ok(j);
+            rank += (vj && (u < v || (u == v && j < i))) ? 1 : 0;
+        }
+        if (mine) dst[rank] = v;
+        total += __builtin_popcountll(__ballot(mine));
+    }
+    wave_sync();
+    return total;
+}
+
+// TS33C/stream_decoder.py:112-202
+__device__ inline void wave_decode_ts33c(const WaveLds& L, int n, double reset_limit, DecState* st,
+                                         const BackParams& P, sdr_frame* f /* lane 0 writes */)
+{
+    const int lane = threadIdx.x & 63;
+    const double* cur = L.cur;
+    const int np_ = (n + 1) / 2, ng = n / 2;
+    auto pulse = [&](int j) { return cur[2 * j]; };
+    auto all_ok = [&](int) { return true; };
+    wave_rank_sort(pulse, all_ok, np_, L.scratch);
+    const double plim = hist_auto_mid_edge(L.scratch, np_, P.pow_m13, P.log2n);
+    wave_sync();
+    auto gap = [&](int j) { return cur[2 * j + 1]; };
+    auto gap_ok = [&](int j) {
+        double g = cur[2 * j + 1];
+        return g > 0.0 && !(g > reset_limit);
+    };
+    const int ngf = wave_rank_sort(gap, gap_ok, ng, L.scratch);
+    const double glim = hist_auto_mid_edge(L.scratch, ngf, P.pow_m13, P.log2n);
+    wave_sync();
+    st->pulse_short_limit = plim;
+    st->gap_short_limit = glim;
+
+    L.words[lane] = 0;
+    wave_sync();
+    int base_r = 0;
+    for (int k0 = 0; k0 < n; k0 += 64) {
+        const int k = k0 + lane;
+        bool valid = false;
+        int bit = 0;
+        if (k < n) {
+            if ((k & 1) == 0) {
+                bit = (cur[k] < plim) ? 1 : 0;
+                valid = true;
+            } else {
+                double g = cur[k];
+                if (g > reset_limit) g = 0.0;
+                valid = !(g < glim);  // short gaps (255) are removed
+            }
+        }
+        const unsigned long long m = __ballot(valid);
+        const int r = base_r + __builtin_popcountll(m & lanemask_lt());
+        if (valid) {
+            if ((r + 1) % 9 == 0) {
+                const int pi = (r + 1) / 9 - 1;
+                if (pi < 256) L.par[pi] = (unsigned char)bit;
+            } else {
+                const int d = r - r / 9;
+                if (!bit && d < 2048) atomicOr(&L.words[d >> 5], 1u << (d & 31));  // reverse + invert
+            }
+        }
+        base_r += __builtin_popcountll(m);
+    }
+    wave_sync();
+    const int nraw = base_r, npar = nraw / 9, ndata = nraw - npar;
+    int status;
+    int nbytes = 0;
+    if ((ndata % 8) != 0)
+        status = SDR_FRAME_BAD_LENGTH;
+    else {
+        nbytes = ndata / 8;
+        bool par_ok = true;
+        if (npar == nbytes) {
+            for (int i0 = 0; i0 < nbytes; i0 += 64) {
+                const int i = i0 + lane;
+                bool bad = false;
+                if (i < nbytes) {
+                    unsigned int b = (L.words[(i >> 2) & 63] >> (8 * (i & 3))) & 0xffu;
+                    bool even = (__builtin_popcount(b) & 1) == 0;
+                    bad = even != (L.par[i & 255] == 1);
+                }
+                if (__ballot(bad)) par_ok = false;
+            }
+        }
+        const unsigned int b0 = L.words[0] & 0xffu;
+        if (npar != nbytes || !par_ok)
+            status = SDR_FRAME_PARITY;
+        else if (!(nbytes == 10 && b0 == 0x9f))
+            status = SDR_FRAME_UNKNOWN_HEADER;
+        else
+            status = SDR_FRAME_OK;
+    }
+    if (lane == 0 && f) {
+        f->lim[0] = plim;
+        f->lim[1] = glim;
+        f->nbits = nraw;
+        f->status = status;
+        if (status != SDR_FRAME_BAD_LENGTH) {
+            f->nbytes = nbytes < 16 ? nbytes : 16;
+            unsigned char bytes[16];
+            for (int i = 0; i < 16; ++i) bytes[i] = (unsigned char)((L.words[i >> 2] >> (8 * (i & 3))) & 0xffu);
+            for (int i = 0; i < f->nbytes; ++i) f->bytes[i] = bytes[i];
+            if (status == SDR_FRAME_OK) {
+                int channel = (bytes[1] >> 5) & 0x0F;
+                if (channel >= 5) channel -= 1;
+                int temp = (bytes[5] & 0x0F) * 100 + ((bytes[4] & 0xF0) >> 4) * 10 + (bytes[4] & 0x0F);
+                int sign = (((bytes[5] >> 7) & 0x01) * 2) - 1;
+                f->v[0] = channel;
+                f->v[1] = bytes[1] & 0x0F;
+                f->v[2] = ((bytes[5] >> 6) & 0x01) == 1;
+                f->v[3] = ((bytes[6] & 0xF0) >> 4) * 10 + (bytes[6] & 0x0F);
+                f->temp_tenths = temp * sign;
+            }
+        }
+    }
+    wave_sync();
+}
+
+// TFA/stream_decoder.py:132-199 (+ NaN guard of analyzer2.grc:897,959-960)
+__device__ inline void wave_decode_tfa(const WaveLds& L, int n0, bool nan_guard, sdr_frame* f)
+{
+    const int lane = threadIdx.x & 63;
+    const double* c = L.cur + (n0 < 6 ? n0 : 6);
+    const int n = n0 < 6 ? 0 : n0 - 6;
+    const int ns = n < 150 ? n : 150;
+    int status = -1;
+    double sym = 0.0;
+    long long nbits = 0;
+    if (ns & 1)
+        status = SDR_FRAME_EXC_RESHAPE;
+    else if (ns == 0)
+        status = nan_guard ? SDR_FRAME_SYMBOL_LENGTH : SDR_FRAME_EXC_NAN;
+    int ds = -1;
+    if (status < 0) {
+        const int npair = ns / 2;
+        for (int i = lane; i < npair; i += 64) L.scratch[i] = c[2 * i] + c[2 * i + 1];
+        wave_sync();
+        sym = np_pairwise_sum_small(L.scratch, npair) / (double)npair;
+        const double thr = sym * 1.5;
+        for (int k0 = 0; k0 < n && ds < 0; k0 += 64) {
+            const int k = k0 + lane;
+            const unsigned long long m = __ballot(k < n && c[k] > thr);
+            if (m) ds = k0 + __builtin_ctzll(m);
+        }
+        if (ds < 0) status = SDR_FRAME_EXC_INDEX;
+    }
+    if (status < 0) {
+        if (lane < 3) L.words[lane] = 0;
+        wave_sync();
+        for (int k0 = ds; k0 < n - 1; k0 += 64) {
+            const int k = k0 + lane;
+            long long cnt = 0;
+            bool one = false;
+            if (k < n - 1) {
+                double w = c[k];
+                one = ((k - ds) & 1) == 0;
+                if (one) {
+                    if (w < sym) w = 0.0;
+                    cnt = (long long)floor(w / sym);
+                } else
+                    cnt = (long long)ceil(w / sym);
+            }
+            long long incl = cnt;  // inclusive prefix sum over the wave
+            for (int off = 1; off < 64; off <<= 1) {
+                long long t = __shfl_up(incl, off);
+                if (lane >= off) incl += t;
+            }
+            const long long start = nbits + incl - cnt;
+            if (one)
+                for (long long b = start; b < start + cnt && b < 88; ++b)
+                    atomicOr(&L.words[b >> 5], 1u << (b & 31));  // per-byte LSB first == bit b of the stream
+            nbits += __shfl(incl, 63);
+        }
+        wave_sync();
+        if (nbits < 88)
+            status = SDR_FRAME_BAD_LENGTH;
+        else {
+            unsigned char bytes[11];
+            for (int i = 0; i < 11; ++i) bytes[i] = (unsigned char)((L.words[i >> 2] >> (8 * (i & 3))) & 0xffu);
+            status = (crc8_31(bytes + 2, 8) == bytes[10]) ? SDR_FRAME_OK : SDR_FRAME_CRC;
+            if (lane == 0 && f) {
+                f->nbytes = 11;
+                for (int i = 0; i < 11; ++i) f->bytes[i] = bytes[i];
+                if (status == SDR_FRAME_OK) {
+                    f->v[0] = ((int)bytes[2] << 8) + bytes[3];
+                    f->v[1] = bytes[6] & 0x7f;
+                    f->v[2] = ((bytes[7] >> 7) & 0x01) == 0;
+                    f->temp_tenths = (bytes[4] & 0x0f) * 100 + ((bytes[5] >> 4) & 0x0f) * 10 + (bytes[5] & 0x0f) - 400;
+                }
+            }
+        }
+    }
+    if (lane == 0 && f) {
+        f->lim[0] = sym;
+        f->nbits = (int)(nbits > 0x7fffffff ? 0x7fffffff : nbits);
+        f->status = status;
+    }
+    wave_sync();
+}
+
+// TS33C/stream_decoder.py:39-110,204-217 on one wavefront
+template <class WF>
+__device__ inline void wave_stream_decode(const BackParams& P, int cap, WF W, const int32_t* pos, long long R,
+                                          int first_level, int last_level, bool any_one, const WaveLds& L,
+                                          DecState* st)
+{
+    const int lane = threadIdx.x & 63;
+    const bool ts33c = (P.decoder == SDR_DEC_TS33C);
+    const double reset_limit = ts33c ? 1550.0 : 500.0;
+    if (!(P.nb > 0 && (any_one || st->n_cur > 0))) {
+        st->state = 0;
+        return;
+    }
+    const int cur_type = first_level;
+    st->chunk_id += 1;
+    long long n_over = 0;
+    for (long long k0 = 0; k0 < R; k0 += 64) {
+        const long long k = k0 + lane;
+        n_over += __builtin_popcountll(__ballot(k < R && W(k) > reset_limit));
+    }
+    const long long npieces = n_over + 1;
+    const bool size_is_1 = (npieces == 1 && R == 1);
+    if (npieces > 1) st->state = 1;
+    double* cur = L.cur;
+    long long a = 0;
+    for (long long pc = 0; pc < npieces; ++pc) {
+        long long b;
+        if (pc == npieces - 1)
+            b = R;
+        else {
+            b = -1;
+            for (long long k0 = a; b < 0; k0 += 64) {
+                const long long k = k0 + lane;
+                const unsigned long long m = __ballot(k < R && W(k) > reset_limit);
+                if (m) b = k0 + __builtin_ctzll(m) + 1;  // the over-limit width closes the piece
+            }
+        }
+        long long s = a;
+        if (size_is_1 || st->state == 0) ++s;
+        if (s < b) {
+            st->state = 1;
+            if (st->n_cur > 0 && st->prev_type == cur_type) {
+                if (lane == 0) cur[st->n_cur - 1] += W(s);
+                ++s;
+            }
+            const long long room = SDR_CUR_CAP - st->n_cur;
+            long long cnt = b - s;
+            if (cnt > room) {
+                cnt = room;
+                st->overflow |= 4;
+            }
+            for (long long i = lane; i < cnt; i += 64) cur[st->n_cur + i] = W(s + i);
+            st->n_cur += (int)cnt;
+            wave_sync();
+            if (cur[0] > reset_limit) {
+                for (int i0 = 0; i0 < st->n_cur - 1; i0 += 64) {
+                    const int i = i0 + lane;
+                    double v = (i < st->n_cur - 1) ? cur[i + 1] : 0.0;
+                    wave_sync();
+                    if (i < st->n_cur - 1) cur[i] = v;
+                    wave_sync();
+                }
+                st->n_cur--;
+            }
+            if (st->n_cur > 1 && cur[st->n_cur - 1] > reset_limit) {
+                sdr_frame* f = nullptr;
+                if (st->n_frames >= P.max_frames)
+                    st->overflow |= 2;
+                else {
+                    f = P.frames + (long long)cap * P.max_frames + st->n_frames;
+                    st->n_frames++;
+                    if (lane == 0) frame_init(f, cap, P.decoder, pos[b]);
+                }
+                wave_sync();
+                if (f) {
+                    if (ts33c)
+                        wave_decode_ts33c(L, st->n_cur, reset_limit, st, P, f);
+                    else
+                        wave_decode_tfa(L, st->n_cur, P.decoder == SDR_DEC_TFA_GRC, f);
+                }
+                st->n_cur = 0;
+            }
+        } else {
+            st->state = 0;
+        }
+        a = b;
+    }
+    st->prev_type = last_level;
+}

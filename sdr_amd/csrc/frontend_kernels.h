@@ -151,8 +151,29 @@ __global__ void __launch_bounds__(256) k_frontend(FrontParams P)
         return make_float2(0.f, 0.f);
     };
 
+    int lsh = 0;  // LDS index of sample lo_idx
     if (USE_LDS) {
-        for (int i = threadIdx.x; i < count; i += T) lds[i] = fetch(lo_idx + i);
+        // Interior tiles: 16-B direct-to-LDS loads (global_load_lds_dwordx4), no
+        // VGPR round trip, one 1-KiB piece per wave-instruction.  The tile start is
+        // moved down to a 16-B boundary of the capture buffer.
+        const long long gidx = (long long)cap * P.stride + lo_idx;
+        const int odd = (int)(gidx & 1);
+        const long long lo_al = lo_idx - odd;
+        const int pairs = (count + odd + 1) >> 1;
+        const bool interior = P.vec_ok && lo_al >= 0 && (lo_al + 2LL * pairs) <= P.n;
+        if (interior) {
+            lsh = odd;
+            const float2* src = x + lo_al;
+            for (int p0 = (threadIdx.x & ~63); p0 < pairs; p0 += T) {
+                const int p = p0 + lane_id();
+                if (p < pairs)
+                    __builtin_amdgcn_global_load_lds(
+                        (const __attribute__((address_space(1))) void*)(src + 2 * p),
+                        (__attribute__((address_space(3))) void*)(lds + 2 * p0), 16, 0, 0);
+            }
+        } else {
+            for (int i = threadIdx.x; i < count; i += T) lds[i] = fetch(lo_idx + i);
+        }
         __syncthreads();
     }
 
@@ -165,7 +186,7 @@ __global__ void __launch_bounds__(256) k_frontend(FrontParams P)
     if (have_y) {
         const float* __restrict__ rt = P.rtaps;
         if (USE_LDS) {
-            const float2* p = lds + (long long)t * P.D;
+            const float2* p = lds + lsh + (long long)t * P.D;
             if (P.taps_complex) {
                 for (int j = 0; j < P.ntaps; ++j) {
                     float2 s = p[j];

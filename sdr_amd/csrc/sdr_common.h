@@ -37,6 +37,7 @@ struct FrontParams {
     long long nout;         // demod outputs per capture in this call
     long long in0;          // input index of output 0's newest sample
     int hist_len;
+    int vec_ok;             // x is 16-B aligned and stride is even: 16-B direct-to-LDS staging allowed
     int D;
     int ntaps;
     int taps_complex;

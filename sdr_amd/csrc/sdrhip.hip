@@ -312,7 +312,7 @@ static void pick_tile(const sdr_handle* h, int& T, size_t& lds, bool& use_lds)
     use_lds = true;
     for (int i = 0; i < 3; ++i) {
         T = cands[i];
-        lds = ((size_t)(T - 1) * D + nt) * sizeof(float2);
+        lds = ((size_t)(T - 1) * D + nt + 2) * sizeof(float2);  // +2: 16-B aligned tile start
         if (lds <= 40 * 1024) return;
     }
     if (lds <= 60 * 1024) return;
@@ -535,6 +535,7 @@ static int launch_front_and_back(sdr_handle* h, const float2* x, long long strid
         P.nout = g.nout;
         P.in0 = g.in0;
         P.hist_len = hist_len;
+        P.vec_ok = ((((uintptr_t)x) & 15) == 0 && (stride % 2) == 0) ? 1 : 0;
         P.D = c.decim;
         P.ntaps = h->ntaps;
         P.taps_complex = h->rt_complex;

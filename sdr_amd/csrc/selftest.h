@@ -83,8 +83,8 @@ extern "C" SDR_API int sdr_selftest_dec_work(void* p, const int8_t* bits, size_t
         const int first_level = d->raw[0] != 0, last_level = d->raw[nb - 1] != 0;
         const bool any_one = first_level || R > 1;
         if (sd)
-            stream_decode(P, 0, pos.data(), R, first_level, last_level, any_one, d->cur.data(), &d->st,
-                          d->cur_l.data(), d->scratch.data());
+            stream_decode(P, 0, WidthsFromPos{pos.data(), d->rate}, pos.data(), R, first_level, last_level, any_one,
+                          d->cur.data(), &d->st, d->scratch.data());
         else {
             std::vector<unsigned char> sb(512);
             EdgeCtx e{pos.data(), R, nb, first_level, (long long)d->rate};

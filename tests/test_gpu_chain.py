@@ -301,3 +301,44 @@ def test_edge_cases():
         b = c.fetch_bits()
     wb = odsp.ook_chain(iq, taps, 1, 1.0, 0.05, 0.15, 7)
     assert np.array_equal(b, wb) and b[-1] == 1
+
+
+def test_tfa_error_paths_on_gpu():
+    """The reference's latent exceptions come back as frame status codes."""
+    rate = 2000000
+    cases = [(_lib.DEC_TFA, [20, 20, 20, 20, 20, 20, 15, 11, 700], _lib.FRAME_EXC_RESHAPE),
+             (_lib.DEC_TFA, [20, 20, 20, 20, 20, 20, 15, 700], _lib.FRAME_EXC_INDEX),
+             (_lib.DEC_TFA, [20, 20, 20, 20, 20, 20, 15, 11, 15, 700], _lib.FRAME_BAD_LENGTH),
+             (_lib.DEC_TFA_GRC, [20, 20, 20, 20, 20, 700], _lib.FRAME_SYMBOL_LENGTH),
+             (_lib.DEC_TFA, [20, 20, 20, 20, 20, 700], _lib.FRAME_EXC_NAN)]
+    for decoder, widths, want in cases:
+        sym = [(1 - (i & 1), w) for i, w in enumerate(widths)]
+        env = synth.envelope(sym, rate, lead_in_us=600.0).astype(np.int8)
+        with chain.Chain(rate, decoder=decoder, decoder_rate=rate, max_samples=env.size) as c:
+            c.process_bits(env)
+            assert [f.status for f in c.fetch_frames()] == [want]
+
+
+def test_tfa_stream_chunked_on_gpu():
+    rate = 2000000
+    rng = np.random.default_rng(31)
+    pkts, sym = [], []
+    for _ in range(3):
+        p = synth.tfa_packet(ident=int(rng.integers(0, 65536)), temp_c=float(rng.integers(-300, 500)) / 10,
+                             humidity=int(rng.integers(0, 100)), battery_ok=bool(rng.integers(0, 2)))
+        pkts.append(p)
+        sym += synth.tfa_symbols(synth.tfa_bits(p), rng, reset_gap_us=4000.0)
+    env = np.concatenate([synth.envelope(sym, rate, lead_in_us=900.0), np.zeros(1500, np.uint8)]).astype(np.int8)
+    o = odec.TFAStreamDecoder(sample_rate=rate)
+    frames = []
+    with chain.Chain(rate, decoder=chain.DEC_TFA, decoder_rate=rate, max_samples=env.size) as c:
+        for ch in np.array_split(env, 200):
+            c.process_bits(ch)
+            o.work([ch])
+            frames += [_copy(f) for f in c.fetch_frames()]
+            assert c.decoder_state() == [int(o.state == "frame"), int(o.currentSymbols.size),
+                                         int(o.previousSymbolType), o.chunk_id]
+    assert len(frames) == len(o.frames) == 3
+    for of, gf, p in zip(o.frames, frames, pkts):
+        assert_tfa_equal(of, gf)
+        assert gf.packet() == p
