@@ -276,6 +276,7 @@ SDR_HD inline void decode_tfa(const double* cur0, int n0, double* scratch, bool 
 // ---- pigpio-callback rule decoders on run boundaries ---------------------------
 struct EdgeCtx {
     const int32_t* pos;
+    const long long* ticks;  // optional precomputed ticks (LDS); nullptr -> from pos
     long long R;
     long long nb;
     int first_level;
@@ -283,6 +284,7 @@ struct EdgeCtx {
 };
 SDR_HD inline long long tick_of(const EdgeCtx& e, long long k)
 {
+    if (e.ticks) return e.ticks[k];
     return ((long long)e.pos[k] * 1000000LL) / e.rate_hz;
 }
 
@@ -567,169 +569,3 @@ SDR_HD inline void stream_decode(const BackParams& P, int cap, WF W, const int32
     st->prev_type = last_level;  // rawBuffer[-2] (:212)
 }
 
-#if defined(__HIPCC__)
-#include "backend_wave.h"
-#endif
-
-__global__ void __launch_bounds__(BK_THREADS) k_backend(BackParams P)
-{
-    __shared__ int s_cnt[BK_THREADS];
-    __shared__ int s_has[BK_THREADS];
-    __shared__ int s_last[BK_THREADS];
-    __shared__ double s_cur[SDR_CUR_CAP];
-    __shared__ double s_scratch[SDR_CUR_CAP];
-    __shared__ double s_w[SDR_CUR_CAP];
-    __shared__ unsigned int s_words[64];
-    __shared__ unsigned char s_par[256];
-    __shared__ unsigned char s_bits[512];
-    __shared__ long long s_R;
-
-    const int cap = blockIdx.x, tid = threadIdx.x;
-    int8_t* bits = P.bits + (long long)cap * P.bits_stride;
-    DecState* st = P.st + cap;
-
-    if (P.fresh && tid == 0) {
-        st->state = 0;
-        st->n_cur = 0;
-        st->prev_type = 0;
-        st->chunk_id = 0;
-        st->thr_state = P.thr_init;
-        st->overflow = 0;
-        st->pulse_short_limit = 775.0;
-        st->gap_short_limit = 775.0;
-    }
-    if (tid == 0) st->n_frames = 0;
-    __syncthreads();
-
-    // ---- phase 0: hysteresis carries --------------------------------------
-    if (P.tsum) {
-        const TileSum* ts = P.tsum + (long long)cap * P.tiles_per_capture;
-        const int nt = P.tiles_per_capture;
-        const int per = (nt + BK_THREADS - 1) / BK_THREADS;
-        const int t0 = tid * per, t1 = (t0 + per < nt) ? t0 + per : nt;
-        int has = 0, last = 0;
-        for (int i = t0; i < t1; ++i)
-            if (ts[i].first_evt >= 0) {
-                has = 1;
-                last = ts[i].last_state;
-            }
-        s_has[tid] = has;
-        s_last[tid] = last;
-        __syncthreads();
-        int carry = P.use_state_thr ? st->thr_state : P.thr_init;
-        for (int w = tid - 1; w >= 0; --w)
-            if (s_has[w]) {
-                carry = s_last[w];
-                break;
-            }
-        int8_t* wbits = bits + P.patch_off;
-        for (int i = t0; i < t1; ++i) {
-            long long o_beg = (long long)i * P.tile_out;
-            long long o_end = min(P.nout, o_beg + P.tile_out);
-            long long fe = ts[i].first_evt;
-            if (carry == 1) {
-                long long e = fe >= 0 ? fe : o_end;
-                long long o = o_beg < P.keep_c0 ? P.keep_c0 : o_beg;
-                if (P.keep_n > 1) {
-                    long long r = (o - P.keep_c0) % P.keep_n;
-                    if (r) o += P.keep_n - r;
-                }
-                for (; o < e; o += P.keep_n) wbits[(o - P.keep_c0) / P.keep_n] = 1;
-            }
-            if (fe >= 0) carry = ts[i].last_state;
-        }
-        __syncthreads();
-        // the thread that owns the last tile hands the carry-out to thread 0
-        // through LDS; thread 0 is the only writer of *st
-        if ((t0 < nt && t1 == nt) || (nt == 0 && tid == 0)) s_cnt[0] = carry;
-        __syncthreads();
-        if (tid == 0) st->thr_state = s_cnt[0];
-    }
-    if (!P.run_decoder || P.decoder == SDR_DEC_NONE) return;
-    __syncthreads();
-
-    // ---- phase 1: run-length ------------------------------------------------
-    const long long nb = P.nb;
-    int32_t* pos = P.runs + (long long)cap * (P.runs_cap + 2);
-    const long long per = (nb + BK_THREADS - 1) / BK_THREADS;
-    const long long j0 = (long long)tid * per, j1 = min(nb, j0 + per);
-    int cnt = 0;
-    {
-        int prev = (j0 > 0 && j0 < nb) ? bits[j0 - 1] : (nb > 0 ? bits[0] : 0);
-        for (long long j = j0; j < j1; ++j) {
-            int b = bits[j];
-            cnt += (b != prev);
-            prev = b;
-        }
-    }
-    s_cnt[tid] = cnt;
-    __syncthreads();
-    if (tid == 0) {
-        int acc = 0;
-        for (int i = 0; i < BK_THREADS; ++i) {
-            int c = s_cnt[i];
-            s_cnt[i] = acc;
-            acc += c;
-        }
-        long long R = (long long)acc + 1;
-        if (nb == 0) R = 0;
-        if (R > P.runs_cap) {
-            st->overflow |= 1;
-            R = P.runs_cap;
-        }
-        s_R = R;
-        pos[0] = 0;
-    }
-    __syncthreads();
-    const long long R = s_R;
-    {
-        long long w = 1 + s_cnt[tid];
-        int prev = (j0 > 0 && j0 < nb) ? bits[j0 - 1] : (nb > 0 ? bits[0] : 0);
-        for (long long j = j0; j < j1; ++j) {
-            int b = bits[j];
-            if (b != prev) {
-                if (w < R) pos[w] = (int32_t)j;
-                ++w;
-            }
-            prev = b;
-        }
-    }
-    if (tid == 0) pos[R] = (int32_t)nb;
-    __syncthreads();
-    // run widths and the pending symbols into LDS (all threads), then one
-    // thread walks them: every access of the sequential part is an LDS access
-    const bool w_in_lds = R <= SDR_CUR_CAP;
-    if (w_in_lds)
-        for (long long k = tid; k < R; k += BK_THREADS) s_w[k] = run_width(pos, k, P.dec_rate);
-    double* gcur = P.cur + (long long)cap * SDR_CUR_CAP;
-    {
-        const int npend = st->n_cur;
-        for (int k = tid; k < npend && k < SDR_CUR_CAP; k += BK_THREADS) s_cur[k] = gcur[k];
-    }
-    __syncthreads();
-    if (tid >= 64) return;
-
-    // ---- phase 2: decode on wavefront 0 (backend_wave.h) ---------------------
-    if (nb == 0) return;
-    DecState ls = *st;
-    const int first_level = bits[0] != 0, last_level = bits[nb - 1] != 0;
-    const bool any_one = first_level || R > 1;
-    if (P.decoder <= SDR_DEC_TFA_GRC) {
-        WaveLds L{s_cur, s_scratch, s_words, s_par};
-        if (w_in_lds)
-            wave_stream_decode(P, cap, WidthsArray{s_w}, pos, R, first_level, last_level, any_one, L, &ls);
-        else
-            wave_stream_decode(P, cap, WidthsFromPos{pos, P.dec_rate}, pos, R, first_level, last_level, any_one, L,
-                               &ls);
-        for (int k = tid; k < ls.n_cur; k += 64) gcur[k] = s_cur[k];
-    } else if (tid == 0) {
-        EdgeCtx e{pos, R, nb, first_level, (long long)P.dec_rate};
-        if (P.decoder == SDR_DEC_SOMFY)
-            rule_somfy(e, P, &ls, cap, s_bits);
-        else if (P.decoder == SDR_DEC_BERNER)
-            rule_berner(e, P, &ls, cap, s_bits);
-        else if (P.decoder == SDR_DEC_MUMBI)
-            rule_mumbi(e, P, &ls, cap, s_bits);
-    }
-    if (tid == 0) *st = ls;
-}

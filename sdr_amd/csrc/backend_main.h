@@ -1,0 +1,207 @@
+// k_backend: one 256-thread workgroup per capture (or per streaming call).
+// LDS plan (26 KiB -> 6 workgroups per CU, so a 1250-capture batch is one
+// round on 256 CUs):
+//   A  8 KiB  currentSymbols (pending + this call's widths of the open packet)
+//   B  8 KiB  phase 1: the sliced bytes | phase 2: sort scratch
+//   C  8 KiB  phase 0: per-thread carry table | phase 1+: run widths (or ticks)
+#pragma once
+#include "backend_kernels.h"
+#include "backend_wave.h"
+
+#define BK_BYTES_LDS 8192
+
+__global__ void __launch_bounds__(BK_THREADS) k_backend(BackParams P)
+{
+    __shared__ __align__(16) unsigned char s_A[SDR_CUR_CAP * 8];
+    __shared__ __align__(16) unsigned char s_B[SDR_CUR_CAP * 8];
+    __shared__ __align__(16) unsigned char s_C[SDR_CUR_CAP * 8];
+    __shared__ int s_cnt[BK_THREADS];
+    __shared__ int s_wtot[4];
+    __shared__ unsigned int s_words[64];
+    __shared__ unsigned char s_par[256];
+    __shared__ unsigned char s_bits[512];
+
+    double* s_cur = reinterpret_cast<double*>(s_A);
+    double* s_scratch = reinterpret_cast<double*>(s_B);
+    int8_t* s_b = reinterpret_cast<int8_t*>(s_B);
+    double* s_w = reinterpret_cast<double*>(s_C);
+    long long* s_tick = reinterpret_cast<long long*>(s_C);
+    int* s_has = reinterpret_cast<int*>(s_C);
+    int* s_last = s_has + BK_THREADS;
+
+    const int cap = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    int8_t* bits = P.bits + (long long)cap * P.bits_stride;
+    DecState* st = P.st + cap;
+
+    if (tid == 0) {
+        if (P.fresh) {
+            st->state = 0;
+            st->n_cur = 0;
+            st->prev_type = 0;
+            st->chunk_id = 0;
+            st->thr_state = P.thr_init;
+            st->overflow = 0;
+            st->pulse_short_limit = 775.0;
+            st->gap_short_limit = 775.0;
+        }
+        st->n_frames = 0;
+    }
+    __syncthreads();
+
+    // ---- phase 0: hysteresis carries --------------------------------------
+    if (P.tsum) {
+        const TileSum* ts = P.tsum + (long long)cap * P.tiles_per_capture;
+        const int nt = P.tiles_per_capture;
+        const int per = (nt + BK_THREADS - 1) / BK_THREADS;
+        const int t0 = tid * per, t1 = (t0 + per < nt) ? t0 + per : nt;
+        int has = 0, last = 0;
+        for (int i = t0; i < t1; ++i)
+            if (ts[i].first_evt >= 0) {
+                has = 1;
+                last = ts[i].last_state;
+            }
+        // nearest earlier thread that saw an event: ballot inside the wave, a
+        // 4-entry table across waves
+        const unsigned long long mh = __ballot(has), ml = __ballot(last);
+        if (lane == 0) {
+            s_has[wv] = mh != 0;
+            s_last[wv] = mh ? (int)((ml >> (63 - __builtin_clzll(mh))) & 1) : 0;
+        }
+        __syncthreads();
+        int carry = P.use_state_thr ? st->thr_state : P.thr_init;
+        const unsigned long long below = mh & ((1ull << lane) - 1ull);
+        if (below)
+            carry = (int)((ml >> (63 - __builtin_clzll(below))) & 1);
+        else
+            for (int w = wv - 1; w >= 0; --w)
+                if (s_has[w]) {
+                    carry = s_last[w];
+                    break;
+                }
+        int8_t* wbits = bits + P.patch_off;
+        for (int i = t0; i < t1; ++i) {
+            long long o_beg = (long long)i * P.tile_out;
+            long long o_end = o_beg + P.tile_out < P.nout ? o_beg + P.tile_out : P.nout;
+            long long fe = ts[i].first_evt;
+            if (carry == 1) {
+                long long e = fe >= 0 ? fe : o_end;
+                long long o = o_beg < P.keep_c0 ? P.keep_c0 : o_beg;
+                if (P.keep_n > 1) {
+                    long long r = (o - P.keep_c0) % P.keep_n;
+                    if (r) o += P.keep_n - r;
+                }
+                for (; o < e; o += P.keep_n) wbits[(o - P.keep_c0) / P.keep_n] = 1;
+            }
+            if (fe >= 0) carry = ts[i].last_state;
+        }
+        __syncthreads();
+        // the owner of the last tile hands the carry-out to thread 0 through LDS;
+        // thread 0 is the only writer of *st
+        if ((t0 < nt && t1 == nt) || (nt == 0 && tid == 0)) s_cnt[0] = carry;
+        __syncthreads();
+        if (tid == 0) st->thr_state = s_cnt[0];
+    }
+    if (!P.run_decoder || P.decoder == SDR_DEC_NONE) return;
+    __syncthreads();
+
+    // ---- phase 1: run-length ------------------------------------------------
+    const long long nb = P.nb;
+    int32_t* pos = P.runs + (long long)cap * (P.runs_cap + 2);
+    const bool b_in_lds = nb <= BK_BYTES_LDS && ((reinterpret_cast<uintptr_t>(bits) & 15) == 0);
+    if (b_in_lds) {
+        // 16-B loads; the tail read stays inside the capture's 64-B padded row
+        for (long long i = (long long)tid * 16; i < nb; i += BK_THREADS * 16)
+            *reinterpret_cast<int4*>(s_b + i) = *reinterpret_cast<const int4*>(bits + i);
+        __syncthreads();
+    }
+    const int8_t* bb = b_in_lds ? s_b : bits;
+    const long long per = (nb + BK_THREADS - 1) / BK_THREADS;
+    const long long j0 = (long long)tid * per, j1 = (j0 + per < nb) ? j0 + per : nb;
+    int cnt = 0;
+    {
+        int prev = (j0 > 0 && j0 < nb) ? bb[j0 - 1] : (nb > 0 ? bb[0] : 0);
+        for (long long j = j0; j < j1; ++j) {
+            int b = bb[j];
+            cnt += (b != prev);
+            prev = b;
+        }
+    }
+    // block exclusive scan of the per-thread edge counts
+    int incl = cnt;
+    for (int off = 1; off < 64; off <<= 1) {
+        int t = __shfl_up(incl, off);
+        if (lane >= off) incl += t;
+    }
+    if (lane == 63) s_wtot[wv] = incl;
+    __syncthreads();
+    int wbase = 0, total = 0;
+    for (int w = 0; w < 4; ++w) {
+        if (w < wv) wbase += s_wtot[w];
+        total += s_wtot[w];
+    }
+    long long R = (long long)total + 1;
+    if (nb == 0) R = 0;
+    bool runs_overflow = false;
+    if (R > P.runs_cap) {
+        runs_overflow = true;
+        R = P.runs_cap;
+    }
+    const bool w_in_lds = R <= SDR_CUR_CAP;
+    const int first_level = nb > 0 ? (bb[0] != 0) : 0, last_level = nb > 0 ? (bb[nb - 1] != 0) : 0;
+    if (tid == 0) pos[0] = 0;
+    {
+        long long w = 1 + wbase + incl - cnt;
+        int prev = (j0 > 0 && j0 < nb) ? bb[j0 - 1] : (nb > 0 ? bb[0] : 0);
+        for (long long j = j0; j < j1; ++j) {
+            int b = bb[j];
+            if (b != prev) {
+                if (w < R) pos[w] = (int32_t)j;
+                ++w;
+            }
+            prev = b;
+        }
+    }
+    if (tid == 0) pos[R] = (int32_t)nb;
+    __syncthreads();  // pos[] (global) written by this block is read back below
+    if (nb == 0) return;
+
+    // run widths (stream decoders) or edge ticks (callback rules) into LDS
+    const bool stream_dec = P.decoder <= SDR_DEC_TFA_GRC;
+    if (w_in_lds) {
+        if (stream_dec)
+            for (long long k = tid; k < R; k += BK_THREADS) s_w[k] = run_width(pos, k, P.dec_rate);
+        else
+            for (long long k = tid; k < R; k += BK_THREADS)
+                s_tick[k] = ((long long)pos[k] * 1000000LL) / (long long)P.dec_rate;
+    }
+    double* gcur = P.cur + (long long)cap * SDR_CUR_CAP;
+    if (stream_dec) {
+        const int npend = st->n_cur;
+        for (int k = tid; k < npend && k < SDR_CUR_CAP; k += BK_THREADS) s_cur[k] = gcur[k];
+    }
+    __syncthreads();
+    if (tid >= 64) return;
+
+    // ---- phase 2: decode on wavefront 0 ----------------------------------------
+    DecState ls = *st;
+    if (runs_overflow) ls.overflow |= 1;
+    const bool any_one = first_level || R > 1;
+    if (stream_dec) {
+        WaveLds L{s_cur, s_scratch, s_words, s_par};
+        if (w_in_lds)
+            wave_stream_decode(P, cap, WidthsArray{s_w}, pos, R, first_level, last_level, any_one, L, &ls);
+        else
+            wave_stream_decode(P, cap, WidthsFromPos{pos, P.dec_rate}, pos, R, first_level, last_level, any_one, L,
+                               &ls);
+        for (int k = tid; k < ls.n_cur; k += 64) gcur[k] = s_cur[k];
+    } else if (tid == 0) {
+        EdgeCtx e{pos, w_in_lds ? s_tick : nullptr, R, nb, first_level, (long long)P.dec_rate};
+        if (P.decoder == SDR_DEC_SOMFY)
+            rule_somfy(e, P, &ls, cap, s_bits);
+        else if (P.decoder == SDR_DEC_BERNER)
+            rule_berner(e, P, &ls, cap, s_bits);
+        else if (P.decoder == SDR_DEC_MUMBI)
+            rule_mumbi(e, P, &ls, cap, s_bits);
+    }
+    if (tid == 0) *st = ls;
+}

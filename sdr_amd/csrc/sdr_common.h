@@ -6,7 +6,7 @@
 #include "../../include/sdrhip.h"
 
 #define SDR_MAX_POW_TABLE 4096   // n^(-1/3), log2(n) tables for np.histogram "auto"
-#define SDR_CUR_CAP 2048         // pending symbols (currentSymbols) per stream
+#define SDR_CUR_CAP 1024         // pending symbols (currentSymbols) per stream
 #define SDR_NCO_TAB 1024
 
 // per-tile hysteresis summary written by the front-end kernels

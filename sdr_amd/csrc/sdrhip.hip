@@ -12,6 +12,7 @@
 #include "sdr_common.h"
 #include "frontend_kernels.h"
 #include "backend_kernels.h"
+#include "backend_main.h"
 #include "fm_kernels.h"
 
 #ifndef M_PI

@@ -1,0 +1,111 @@
+"""The Python mirrors of the reference's decoder entry points (sdr_amd.ts33c /
+sdr_amd.tfa / blocks.somfy_decode) against the oracle: same prints, same
+attributes, same work() return values -- the tests read like a user of
+TS33C/stream_decoder.py main() / the GRC epy block would use them."""
+import numpy as np
+import pytest
+
+from oracle import decoders as odec
+from sdr_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _readme_bits(kat):
+    k = kat["ts33c_readme"]
+    runs = [np.zeros(600, np.int8)]
+    for p, g in zip(k["pulses"], k["gaps"]):
+        runs += [np.ones(p, np.int8), np.zeros(g, np.int8)]
+    return np.concatenate(runs + [np.zeros(1000, np.int8)])
+
+
+def test_ts33c_streamdecoder_main(kat, capsys):
+    """TS33C/stream_decoder.py:222-235 main(): array_split(raw, 100) -> work([chunk])."""
+    from sdr_amd import ts33c
+    raw = np.concatenate([_readme_bits(kat)] * 3)
+    decoder = ts33c.StreamDecoder(sample_rate=250000, debug_level=ts33c.ERROR)
+    o = odec.TS33CStreamDecoder(sample_rate=250000, debug_level=1)
+    for chunk in np.array_split(raw, 100):
+        assert decoder.work([chunk]) is None
+        o.work([chunk])
+        assert (decoder.state, decoder.chunk_id, decoder.previousSymbolType) == (o.state, o.chunk_id, o.previousSymbolType)
+    out = capsys.readouterr().out.splitlines()
+    assert out == o.prints == ["Temperature: 21.6°C", "Humidity: 39%"] * 3
+    assert decoder.temperature == o.temperature == 21.6 and decoder.humidity == o.humidity == 39
+    assert decoder.pulse_short_limit == o.pulse_short_limit and decoder.gap_short_limit == o.gap_short_limit
+    assert [f["packet"] for f in decoder.frames] == [f["packet"] for f in o.frames]
+    decoder.close()
+
+
+def test_ts33c_debug_strings(capsys):
+    """Error paths print the reference's strings at debug_level >= ERROR."""
+    from sdr_amd import ts33c
+    rng = np.random.default_rng(4)
+    pkt = synth.ts33c_packet(**synth.random_ts33c_fields(rng))
+    bits = synth.ts33c_bits(pkt)
+    bad = list(bits)
+    bad[17] ^= 1   # break a parity bit
+    env = synth.envelope(synth.ts33c_symbols(bits[:81] + [1]) + synth.ts33c_symbols(bits), 20000, lead_in_us=5000.0)
+    decoder = ts33c.StreamDecoder(debug_level=ts33c.ERROR)
+    o = odec.TS33CStreamDecoder(debug_level=1)
+    decoder.work([env.astype(np.int8)])
+    o.work([env.astype(np.int8)])
+    out = capsys.readouterr().out.splitlines()
+    assert [f["status"] for f in decoder.frames] == [f["status"] for f in o.frames]
+    assert len(o.frames) == 2 and o.frames[1]["status"] == "ok" and o.frames[0]["status"] != "ok"
+    assert out[0] == o.frames[0]["status"]
+    assert out[1:] == o.prints
+    decoder.close()
+
+
+def test_ts33c_epy_block_work(kat):
+    """blk.work(input_items, output_items): fills every output element with the
+    last temperature / humidity and returns len(output_items[0])."""
+    from sdr_amd import ts33c
+    b = ts33c.blk(sample_rate=250000)
+    assert b.name() == 'Decoder Block' and b.in_sig == [np.byte] and b.out_sig == [np.float32, np.float32]
+    raw = _readme_bits(kat)
+    for chunk in np.array_split(raw, 7):
+        out0 = np.full(chunk.size, -1, np.float32)
+        out1 = np.full(chunk.size, -1, np.float32)
+        n = b.work([chunk], [out0, out1])
+        assert n == chunk.size
+        assert np.all(out0 == np.float32(b.temperature)) and np.all(out1 == np.float32(b.humidity))
+    assert b.temperature == 21.6 and b.humidity == 39
+
+
+def test_tfa_streamdecoder_main(kat, capsys):
+    """TFA/stream_decoder.py:220-234 main(): sample_rate=2000000, array_split(raw, 200)."""
+    from sdr_amd import tfa
+    pkt = bytes.fromhex(kat["tfa_readme"]["packet_hex"])
+    sym = synth.tfa_symbols(synth.tfa_bits(pkt), reset_gap_us=4000.0)
+    raw = np.concatenate([synth.envelope(sym, 2e6, lead_in_us=900.0), np.zeros(2000, np.uint8)]).astype(np.int8)
+    decoder = tfa.StreamDecoder(sample_rate=2000000, debug_level=0)
+    o = odec.TFAStreamDecoder(sample_rate=2000000)
+    for chunk in np.array_split(raw, 200):
+        decoder.work([chunk])
+        o.work([chunk])
+    out = capsys.readouterr().out.splitlines()
+    assert out == o.prints == ["Temperature: 21.4°C", "Humidity: 54%"]
+    assert (decoder.identifier, decoder.temperature, decoder.humidity, decoder.battery_ok) == (
+        o.identifier, o.temperature, o.humidity, o.battery_ok) == ("71C9", o.temperature, 54, True)
+    assert tfa.StreamDecoder.crc8(bytearray(pkt[2:10])) == pkt[10]
+    # the reference's latent exceptions surface as the same exception types
+    bad = synth.envelope([(1 - (i & 1), w) for i, w in enumerate([20, 20, 20, 20, 20, 20, 15, 11, 700])], 2e6,
+                         lead_in_us=600.0).astype(np.int8)
+    d2 = tfa.StreamDecoder(sample_rate=2000000)
+    with pytest.raises(ValueError):
+        d2.work([bad])
+    decoder.close()
+    d2.close()
+
+
+def test_somfy_decode_kat(kat):
+    """somfy/decoder.py on its own array literal (somfy/decoder.py:27)."""
+    from sdr_amd import blocks
+    k = kat["somfy_stop"]
+    r = blocks.somfy_decode(k["manchester"])
+    want = odec.somfy_decode(k["manchester"])
+    assert r == want
+    assert r["payload"].hex() == k["payload_hex"] and r["frame"].hex() == k["frame_hex"] and r["checksum_ok"]
+    assert (r["control"], r["rolling_code"], r["address"]) == (1, 5, 0x365240)
