@@ -202,6 +202,38 @@ SDR_API int sdr_profile_read(sdr_handle* h, float* front_ms, float* back_ms, int
 SDR_API int sdr_export_frames(sdr_handle* h, void* frames_dev, size_t frames_bytes, void* counts_dev,
                               size_t counts_bytes);
 
+/* ---- FM-Radio chain (BASELINE.json configs[1]) --------------------------------
+ * ref: FM-Radio/FM-Radio.grc:2903-2964 wiring: freq_xlating_fir_filter_ccc
+ * (taps 1, center_freq -shift) -> rational_resampler_ccc 1/int(samp_rate/500e3)
+ * -> low_pass_filter (Blackman) -> analog_wfm_rcv (quadrature_demod ->
+ * fir_filter_fff audio_decimation -> fm_deemph 75 us) -> rational_resampler_fff
+ * 48/50 -> multiply_const(volume).  One call = one capture from stream start. */
+typedef struct sdr_fm_cfg {
+    double sample_rate;      /* samp_rate of the IQ stream */
+    double center_freq;      /* freq_xlating center_freq (= -shift in the GRC) */
+    int32_t resamp_decim;    /* int(samp_rate/500e3) */
+    int32_t audio_decim;     /* wfm_rcv audio_decimation (10) */
+    double lpf_fs, lpf_fc, lpf_tw; /* low_pass_filter as the GRC declares it (2e6, 400e3, 200e3, Blackman) */
+    double quad_rate;        /* wfm_rcv quad_rate as declared (500e3) */
+    double tau;              /* de-emphasis time constant (75e-6) */
+    int32_t audio_interp;    /* rational_resampler_fff interpolation (48) */
+    int32_t audio_decimation;/* rational_resampler_fff decimation (50) */
+    float volume;            /* multiply_const */
+    int32_t pad_;
+    uint64_t max_samples;    /* IQ samples per call */
+} sdr_fm_cfg;
+
+typedef struct sdr_fm sdr_fm;
+SDR_API int sdr_fm_create(const sdr_fm_cfg* cfg, sdr_fm** out);
+SDR_API int sdr_fm_destroy(sdr_fm* h);
+SDR_API int sdr_fm_set_stream(sdr_fm* h, void* hip_stream);
+/* iq: n complex64 samples (host or device); n_audio receives the audio sample count. */
+SDR_API int sdr_fm_process(sdr_fm* h, const void* iq, size_t n, int is_device_ptr, size_t* n_audio);
+/* stage outputs of the last call: 0 resampled complex (pairs), 1 discriminator,
+ * 2 audio FIR, 3 de-emphasis, 4 final audio.  out may be NULL to query *n (floats). */
+SDR_API int sdr_fm_fetch(sdr_fm* h, int stage, float* out, size_t cap, size_t* n);
+SDR_API const char* sdr_fm_last_error(sdr_fm* h);
+
 SDR_API int sdr_version(void);
 
 #ifdef __cplusplus

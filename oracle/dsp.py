@@ -282,3 +282,23 @@ def ook_chain(iq, taps, D, gain, lo, hi, keep_n, fc=0.0, fs=1.0, return_mag=Fals
     if return_mag:
         return bits[:k].copy(), mag[:nout]
     return bits[:k].copy()
+
+
+def fm_radio_chain(iq, samp_rate=2e6, shift=200e3, volume=1.0, lpf=(2e6, 400e3, 200e3), quad_rate=500e3,
+                   audio_decimation=10, tau=75e-6, audio_resample=(48, 50)):
+    """FM-Radio/FM-Radio.grc:2903-2964 block after block (each its own pass, as
+    the GNU Radio scheduler runs it).  Returns the five stage outputs."""
+    D = int(samp_rate / 500e3)
+    x = freq_xlating_fir(iq, [1.0], -shift, samp_rate, 1)
+    y0 = fir_ccf(x, resampler_taps(1, D) if D > 1 else np.ones(1, np.float32), D)
+    y1 = fir_ccf(y0, low_pass(1.0, lpf[0], lpf[1], lpf[2], WIN_BLACKMAN), 1)
+    gain = np.float32(quad_rate / (2 * np.pi * 75e3))
+    q = quad_demod(y1, gain)
+    audio_rate = quad_rate / audio_decimation
+    width = audio_rate / 32
+    a2 = fir_fff(q, low_pass(1.0, quad_rate, audio_rate / 2 - width, width, WIN_HAMMING), audio_decimation)
+    a3 = fm_deemph(a2, audio_rate, tau)
+    g = int(np.gcd(audio_resample[0], audio_resample[1]))
+    L, M = audio_resample[0] // g, audio_resample[1] // g
+    a4 = resample(a3, resampler_taps(L, M), L, M) * np.float32(volume)
+    return y0, q, a2, a3, a4.astype(np.float32)

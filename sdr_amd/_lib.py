@@ -95,6 +95,25 @@ class Out(C.Structure):
     ]
 
 
+class FmCfg(C.Structure):
+    _fields_ = [
+        ("sample_rate", C.c_double),
+        ("center_freq", C.c_double),
+        ("resamp_decim", C.c_int32),
+        ("audio_decim", C.c_int32),
+        ("lpf_fs", C.c_double),
+        ("lpf_fc", C.c_double),
+        ("lpf_tw", C.c_double),
+        ("quad_rate", C.c_double),
+        ("tau", C.c_double),
+        ("audio_interp", C.c_int32),
+        ("audio_decimation", C.c_int32),
+        ("volume", C.c_float),
+        ("pad_", C.c_int32),
+        ("max_samples", C.c_uint64),
+    ]
+
+
 #: every symbol include/sdrhip.h declares (checked by tests/test_abi.py)
 EXPORTS = [
     "sdr_firdes_low_pass", "sdr_resampler_taps", "sdr_create", "sdr_destroy", "sdr_set_taps",
@@ -102,6 +121,8 @@ EXPORTS = [
     "sdr_process_bits", "sdr_batch_process", "sdr_fetch_frames", "sdr_fetch_bits", "sdr_fetch_demod",
     "sdr_decoder_state", "sdr_timer_start", "sdr_timer_stop", "sdr_timer_elapsed_ms", "sdr_version",
     "sdr_profile_enable", "sdr_profile_read", "sdr_export_frames",
+    "sdr_fm_create", "sdr_fm_destroy", "sdr_fm_set_stream", "sdr_fm_process", "sdr_fm_fetch",
+    "sdr_fm_last_error",
 ]
 
 _lib = None
@@ -162,6 +183,18 @@ def load():
     L.sdr_profile_read.argtypes = [H, fp, fp, C.c_int, C.POINTER(C.c_int)]
     L.sdr_export_frames.restype = C.c_int
     L.sdr_export_frames.argtypes = [H, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    L.sdr_fm_create.restype = C.c_int
+    L.sdr_fm_create.argtypes = [C.POINTER(FmCfg), C.POINTER(H)]
+    L.sdr_fm_destroy.restype = C.c_int
+    L.sdr_fm_destroy.argtypes = [H]
+    L.sdr_fm_set_stream.restype = C.c_int
+    L.sdr_fm_set_stream.argtypes = [H, C.c_void_p]
+    L.sdr_fm_process.restype = C.c_int
+    L.sdr_fm_process.argtypes = [H, C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_size_t)]
+    L.sdr_fm_fetch.restype = C.c_int
+    L.sdr_fm_fetch.argtypes = [H, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.sdr_fm_last_error.restype = C.c_char_p
+    L.sdr_fm_last_error.argtypes = [H]
     # host-compiled test hooks (csrc/selftest.h); not used by the product path
     L.sdr_selftest_hist_mid_edge.restype = C.c_int
     L.sdr_selftest_hist_mid_edge.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double)]

@@ -1,1 +1,224 @@
+// Host side of the FM-Radio chain (sdr_fm_* in include/sdrhip.h).  The two
+// complex stages reuse k_frontend through two internal chain handles:
+//   A: input pre-rotation (xlating taps=[1]) + rational_resampler_ccc 1/D  -> complex
+//   B: low_pass_filter (33 taps) + quadrature_demod                         -> float
+// then k_fir_fff_decim, k_deemph, k_resample_fff.
 #pragma once
+
+struct sdr_fm {
+    sdr_fm_cfg cfg;
+    sdr_handle* A = nullptr;
+    sdr_handle* B = nullptr;
+    hipStream_t stream = nullptr;
+    std::string err;
+    float *d_ataps = nullptr, *d_rtaps = nullptr;  // audio FIR (reversed), resampler taps
+    int n_ataps = 0, n_rtaps = 0, L = 1, M = 1;
+    double b0 = 0, p1 = 0;
+    float *d_a2 = nullptr, *d_a3 = nullptr, *d_audio = nullptr;
+    long long n1 = 0, n2 = 0, n4 = 0, cap2 = 0, cap4 = 0;
+};
+
+static int fm_fail(sdr_fm* h, int code, const std::string& msg)
+{
+    if (h) h->err = msg;
+    g_err = msg;
+    return code;
+}
+
+#define FMCHK(h, call)                                                                          \
+    do {                                                                                        \
+        hipError_t e_ = (call);                                                                 \
+        if (e_ != hipSuccess)                                                                   \
+            return fm_fail(h, SDR_E_HIP, std::string(#call) + ": " + hipGetErrorString(e_));    \
+    } while (0)
+
+extern "C" const char* sdr_fm_last_error(sdr_fm* h) { return h ? h->err.c_str() : g_err.c_str(); }
+
+extern "C" int sdr_fm_destroy(sdr_fm* h)
+{
+    if (!h) return SDR_OK;
+    if (h->A) sdr_destroy(h->A);
+    if (h->B) sdr_destroy(h->B);
+    void* ptrs[] = {h->d_ataps, h->d_rtaps, h->d_a2, h->d_a3, h->d_audio};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    delete h;
+    return SDR_OK;
+}
+
+extern "C" int sdr_fm_create(const sdr_fm_cfg* cfg, sdr_fm** out)
+{
+    if (!cfg || !out) return fm_fail(nullptr, SDR_E_ARG, "sdr_fm_create: null argument");
+    *out = nullptr;
+    if (cfg->resamp_decim < 1 || cfg->audio_decim < 1 || cfg->audio_interp < 1 || cfg->audio_decimation < 1 ||
+        cfg->max_samples < 1 || !(cfg->sample_rate > 0) || !(cfg->quad_rate > 0) || !(cfg->tau > 0))
+        return fm_fail(nullptr, SDR_E_ARG, "sdr_fm_create: bad configuration");
+    sdr_fm* h = new sdr_fm();
+    h->cfg = *cfg;
+    auto body = [&]() -> int {
+        std::vector<float> buf(65536);
+        // A: xlating(taps=[1]) + resampler 1/D (design_filter, Kaiser beta 7)
+        sdr_chain_cfg a;
+        memset(&a, 0, sizeof a);
+        a.sample_rate = cfg->sample_rate;
+        a.center_freq = cfg->center_freq;
+        a.decim = cfg->resamp_decim;
+        a.demod = SDR_DEMOD_NONE;
+        a.keep_n = 1;
+        a.tap_demod = 1;
+        a.max_batch = 1;
+        a.max_frames = 1;
+        a.max_samples = cfg->max_samples;
+        int rc = sdr_create(&a, &h->A);
+        if (rc) return fm_fail(h, rc, std::string("stage A: ") + g_err);
+        h->A->prerotate = true;
+        int nt = sdr_resampler_taps(1, cfg->resamp_decim, 0.0, buf.data(), (int)buf.size());
+        if (cfg->resamp_decim == 1) {
+            buf[0] = 1.0f;
+            nt = 1;
+        }
+        if (nt < 1) return fm_fail(h, SDR_E_ARG, "resampler tap design failed");
+        rc = sdr_set_taps(h->A, buf.data(), nt, 0);
+        if (rc) return fm_fail(h, rc, std::string("stage A taps: ") + h->A->err);
+        {
+            int T;
+            size_t lds;
+            bool ul;
+            pick_tile(h->A, T, lds, ul);
+            if (!ul) return fm_fail(h, SDR_E_ARG, "stage A tile does not fit LDS");
+        }
+        // B: low_pass_filter (Blackman) + quadrature_demod
+        const long long n1max = (long long)(cfg->max_samples / cfg->resamp_decim) + 2;
+        sdr_chain_cfg b;
+        memset(&b, 0, sizeof b);
+        b.sample_rate = cfg->sample_rate / cfg->resamp_decim;
+        b.decim = 1;
+        b.demod = SDR_DEMOD_QUAD;
+        b.demod_gain = (float)(cfg->quad_rate / (2 * M_PI * 75e3));
+        b.keep_n = 1;
+        b.tap_demod = 1;
+        b.max_batch = 1;
+        b.max_frames = 1;
+        b.max_samples = (uint64_t)n1max;
+        rc = sdr_create(&b, &h->B);
+        if (rc) return fm_fail(h, rc, std::string("stage B: ") + g_err);
+        h->B->skip_slice = true;
+        nt = sdr_firdes_low_pass(1.0, cfg->lpf_fs, cfg->lpf_fc, cfg->lpf_tw, SDR_WIN_BLACKMAN, 6.76, buf.data(),
+                                 (int)buf.size());
+        if (nt < 1) return fm_fail(h, SDR_E_ARG, "low_pass_filter design failed");
+        rc = sdr_set_taps(h->B, buf.data(), nt, 0);
+        if (rc) return fm_fail(h, rc, std::string("stage B taps: ") + h->B->err);
+        // wfm_rcv audio filter: low_pass(1, quad_rate, audio_rate/2 - width, width, HAMMING)
+        const double audio_rate = cfg->quad_rate / cfg->audio_decim;
+        const double width = audio_rate / 32;
+        nt = sdr_firdes_low_pass(1.0, cfg->quad_rate, audio_rate / 2 - width, width, SDR_WIN_HAMMING, 6.76,
+                                 buf.data(), (int)buf.size());
+        if (nt < 1) return fm_fail(h, SDR_E_ARG, "audio filter design failed");
+        h->n_ataps = nt;
+        std::vector<float> rt(nt);
+        for (int k = 0; k < nt; ++k) rt[nt - 1 - k] = buf[k];
+        FMCHK(h, dev_alloc((void**)&h->d_ataps, nt * sizeof(float)));
+        FMCHK(h, hipMemcpy(h->d_ataps, rt.data(), nt * sizeof(float), hipMemcpyHostToDevice));
+        // fm_deemph(audio_rate, tau)
+        {
+            const double fs = audio_rate, w_c = 1.0 / cfg->tau;
+            const double w_ca = 2.0 * fs * tan(w_c / (2.0 * fs));
+            const double k = -w_ca / (2.0 * fs);
+            h->p1 = (1.0 + k) / (1.0 - k);
+            h->b0 = -k / (1.0 - k);
+        }
+        // rational_resampler_fff
+        int g1 = cfg->audio_interp, g2 = cfg->audio_decimation;
+        while (g2) {
+            int t = g1 % g2;
+            g1 = g2;
+            g2 = t;
+        }
+        h->L = cfg->audio_interp / g1;
+        h->M = cfg->audio_decimation / g1;
+        nt = sdr_resampler_taps(h->L, h->M, 0.0, buf.data(), (int)buf.size());
+        if (nt < 1) return fm_fail(h, SDR_E_ARG, "audio resampler design failed");
+        h->n_rtaps = nt;
+        FMCHK(h, dev_alloc((void**)&h->d_rtaps, nt * sizeof(float)));
+        FMCHK(h, hipMemcpy(h->d_rtaps, buf.data(), nt * sizeof(float), hipMemcpyHostToDevice));
+        h->cap2 = n1max / cfg->audio_decim + 2;
+        h->cap4 = (h->cap2 * h->L + h->M - 1) / h->M + 2;
+        FMCHK(h, dev_alloc((void**)&h->d_a2, (size_t)h->cap2 * sizeof(float)));
+        FMCHK(h, dev_alloc((void**)&h->d_a3, (size_t)h->cap2 * sizeof(float)));
+        FMCHK(h, dev_alloc((void**)&h->d_audio, (size_t)h->cap4 * sizeof(float)));
+        h->stream = h->A->own_stream;
+        sdr_set_stream(h->B, (void*)h->stream);
+        return SDR_OK;
+    };
+    int rc = body();
+    if (rc != SDR_OK) {
+        std::string keep = h->err;
+        sdr_fm_destroy(h);
+        g_err = keep;
+        return rc;
+    }
+    *out = h;
+    return SDR_OK;
+}
+
+extern "C" int sdr_fm_set_stream(sdr_fm* h, void* s)
+{
+    if (!h) return SDR_E_ARG;
+    h->stream = s ? (hipStream_t)s : h->A->own_stream;
+    sdr_set_stream(h->A, (void*)h->stream);
+    sdr_set_stream(h->B, (void*)h->stream);
+    return SDR_OK;
+}
+
+extern "C" int sdr_fm_process(sdr_fm* h, const void* iq, size_t n, int is_dev, size_t* n_audio)
+{
+    if (!h || !iq) return fm_fail(h, SDR_E_ARG, "sdr_fm_process: bad argument");
+    if (n > h->cfg.max_samples) return fm_fail(h, SDR_E_CAPACITY, "sdr_fm_process: capture larger than max_samples");
+    int rc = sdr_batch_process(h->A, iq, n, n, 1, is_dev, nullptr);
+    if (rc) return fm_fail(h, rc, std::string("stage A: ") + h->A->err);
+    h->n1 = h->A->last_nout;
+    h->n2 = h->n1 / h->cfg.audio_decim;
+    h->n4 = (h->n2 * h->L + h->M - 1) / h->M;
+    if (n_audio) *n_audio = (size_t)h->n4;
+    if (h->n1 == 0) return SDR_OK;
+    rc = sdr_batch_process(h->B, h->A->d_tap, (size_t)h->n1, (size_t)h->n1, 1, 1, nullptr);
+    if (rc) return fm_fail(h, rc, std::string("stage B: ") + h->B->err);
+    if (h->n2 == 0) return SDR_OK;
+    {
+        const int T = 256, D = h->cfg.audio_decim;
+        size_t lds = ((size_t)(T - 1) * D + h->n_ataps) * sizeof(float);
+        int blocks = (int)((h->n2 + T - 1) / T);
+        hipLaunchKernelGGL(k_fir_fff_decim, dim3(blocks), dim3(T), lds, h->stream, h->B->d_tap, h->n1, h->n2,
+                           h->d_ataps, h->n_ataps, D, h->d_a2);
+        FMCHK(h, hipGetLastError());
+    }
+    hipLaunchKernelGGL(k_deemph, dim3(1), dim3(DEEMPH_THREADS), 0, h->stream, h->d_a2, h->n2, h->b0, h->p1, h->d_a3);
+    FMCHK(h, hipGetLastError());
+    {
+        int blocks = (int)((h->n4 + 255) / 256);
+        hipLaunchKernelGGL(k_resample_fff, dim3(blocks), dim3(256), 0, h->stream, h->d_a3, h->n2, h->n4, h->d_rtaps,
+                           h->n_rtaps, h->L, h->M, h->cfg.volume, h->d_audio);
+        FMCHK(h, hipGetLastError());
+    }
+    return SDR_OK;
+}
+
+extern "C" int sdr_fm_fetch(sdr_fm* h, int stage, float* out, size_t cap, size_t* n)
+{
+    if (!h || !n) return fm_fail(h, SDR_E_ARG, "sdr_fm_fetch: bad argument");
+    const float* src = nullptr;
+    size_t cnt = 0;
+    switch (stage) {
+    case 0: src = h->A->d_tap; cnt = (size_t)h->n1 * 2; break;
+    case 1: src = h->B->d_tap; cnt = (size_t)h->n1; break;
+    case 2: src = h->d_a2; cnt = (size_t)h->n2; break;
+    case 3: src = h->d_a3; cnt = (size_t)h->n2; break;
+    case 4: src = h->d_audio; cnt = (size_t)h->n4; break;
+    default: return fm_fail(h, SDR_E_ARG, "sdr_fm_fetch: stage 0..4");
+    }
+    FMCHK(h, hipStreamSynchronize(h->stream));
+    *n = cnt;
+    if (!out || cap < cnt || cnt == 0) return SDR_OK;
+    FMCHK(h, hipMemcpy(out, src, cnt * sizeof(float), hipMemcpyDeviceToHost));
+    return SDR_OK;
+}

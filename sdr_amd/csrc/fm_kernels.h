@@ -1,1 +1,113 @@
+// FM-Radio chain back half (FM-Radio/FM-Radio.grc:2903-2964):
+// audio FIR (fir_filter_fff, decimating), fm_deemph (1-pole IIR, double state),
+// rational_resampler_fff (polyphase L/M) * volume.  These run at <= quad_rate
+// (a few 100 kS/s): a few MB per capture, L2-resident; the HBM-bound part of
+// the chain is the first decimating FIR (k_frontend with input pre-rotation).
 #pragma once
+#include "sdr_common.h"
+
+// y[m] = sum_k taps[k] v[m*D-k], zero history, oldest sample first (one fmaf per tap).
+__global__ void __launch_bounds__(256) k_fir_fff_decim(const float* __restrict__ v, long long n_in, long long nout,
+                                                       const float* __restrict__ rtaps, int ntaps, int D,
+                                                       float* __restrict__ out)
+{
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    float* lds = reinterpret_cast<float*>(smem_raw);
+    const int T = blockDim.x;
+    const long long o0 = (long long)blockIdx.x * T;
+    const long long lo = o0 * D - (ntaps - 1);
+    const int count = (T - 1) * D + ntaps;
+    for (int i = threadIdx.x; i < count; i += T) {
+        long long idx = lo + i;
+        lds[i] = (idx >= 0 && idx < n_in) ? v[idx] : 0.f;
+    }
+    __syncthreads();
+    const long long o = o0 + threadIdx.x;
+    if (o >= nout) return;
+    const float* p = lds + (long long)threadIdx.x * D;
+    float a = 0.f;
+#pragma unroll 8
+    for (int j = 0; j < ntaps; ++j) a = __builtin_fmaf(rtaps[j], p[j], a);
+    out[o] = a;
+}
+
+// fm_deemph: y[n] = b0 x[n] + b0 x[n-1] + p1 y[n-1] with double accumulators
+// (gr::filter::iir_filter_ffd).  One workgroup; thread t owns a contiguous chunk.
+// Pass 1 runs the recurrence from y=0 and records (p1^len, y_end); an inclusive
+// scan of the affine maps gives every chunk's true start value; pass 2 re-runs
+// the chunk with it.  The op order inside a chunk is the sequential one; the
+// chunk hand-off differs from it by O(1e-16) relative, far below float32.
+#define DEEMPH_THREADS 1024
+__global__ void __launch_bounds__(DEEMPH_THREADS) k_deemph(const float* __restrict__ x, long long n, double b0,
+                                                           double p1, float* __restrict__ y)
+{
+    __shared__ double sA[DEEMPH_THREADS];  // multiplier of the incoming state
+    __shared__ double sB[DEEMPH_THREADS];  // additive part
+    const int t = threadIdx.x;
+    const long long per = (n + DEEMPH_THREADS - 1) / DEEMPH_THREADS;
+    const long long a0 = (long long)t * per, a1 = (a0 + per < n) ? a0 + per : n;
+    double yp = 0.0, pw = 1.0;
+    double xp = (a0 > 0 && a0 <= n) ? (double)x[a0 - 1] : 0.0;
+    for (long long i = a0; i < a1; ++i) {
+        double xi = (double)x[i];
+        double acc = b0 * xi;
+        acc += b0 * xp;
+        acc += p1 * yp;
+        xp = xi;
+        yp = acc;
+        pw *= p1;
+    }
+    sA[t] = pw;
+    sB[t] = yp;
+    __syncthreads();
+    // inclusive scan of y_out = A*y_in + B (composition, left to right)
+    for (int off = 1; off < DEEMPH_THREADS; off <<= 1) {
+        double A = sA[t], B = sB[t], A2 = 1.0, B2 = 0.0;
+        if (t >= off) {
+            A2 = sA[t - off];
+            B2 = sB[t - off];
+        }
+        __syncthreads();
+        if (t >= off) {
+            sA[t] = A * A2;
+            sB[t] = A * B2 + B;
+        }
+        __syncthreads();
+    }
+    double y0 = (t > 0) ? sB[t - 1] : 0.0;  // state entering this chunk (stream starts at 0)
+    yp = y0;
+    xp = (a0 > 0 && a0 <= n) ? (double)x[a0 - 1] : 0.0;
+    for (long long i = a0; i < a1; ++i) {
+        double xi = (double)x[i];
+        double acc = b0 * xi;
+        acc += b0 * xp;
+        acc += p1 * yp;
+        xp = xi;
+        yp = acc;
+        y[i] = (float)acc;
+    }
+}
+
+// rational_resampler_fff: output m = sum_k h[p + k L] x[i - k], p = (m M) mod L,
+// i = (m M) / L; then multiply_const(volume).  Zero history.
+__global__ void __launch_bounds__(256) k_resample_fff(const float* __restrict__ x, long long n_in, long long nout,
+                                                      const float* __restrict__ taps, int ntaps, int L, int M,
+                                                      float volume, float* __restrict__ out)
+{
+    const long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= nout) return;
+    const long long num = m * (long long)M;
+    const long long i = num / L;
+    const int p = (int)(num % L);
+    const int nt = (ntaps + L - 1) / L;
+    float a = 0.f;
+    for (int j = 0; j < nt; ++j) {  // oldest first: tap k = nt-1-j
+        const int k = nt - 1 - j;
+        const int ti = p + k * L;
+        const float t = ti < ntaps ? taps[ti] : 0.0f;
+        const long long idx = i - k;
+        const float s = (idx >= 0 && idx < n_in) ? x[idx] : 0.0f;
+        a = __builtin_fmaf(t, s, a);
+    }
+    out[m] = volume * a;
+}

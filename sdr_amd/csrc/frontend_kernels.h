@@ -160,7 +160,7 @@ __global__ void __launch_bounds__(256) k_frontend(FrontParams P)
         const int odd = (int)(gidx & 1);
         const long long lo_al = lo_idx - odd;
         const int pairs = (count + odd + 1) >> 1;
-        const bool interior = P.vec_ok && lo_al >= 0 && (lo_al + 2LL * pairs) <= P.n;
+        const bool interior = P.vec_ok && !P.pre_tab && lo_al >= 0 && (lo_al + 2LL * pairs) <= P.n;
         if (interior) {
             lsh = odd;
             const float2* src = x + lo_al;
@@ -170,6 +170,15 @@ __global__ void __launch_bounds__(256) k_frontend(FrontParams P)
                     __builtin_amdgcn_global_load_lds(
                         (const __attribute__((address_space(1))) void*)(src + 2 * p),
                         (__attribute__((address_space(3))) void*)(lds + 2 * p0), 16, 0, 0);
+            }
+        } else if (P.pre_tab) {
+            // freq_xlating_fir_filter with taps=[1] in front of the FIR: rotate
+            // each input sample as it is staged (same ops as the stand-alone block)
+            for (int i = threadIdx.x; i < count; i += T) {
+                const long long idx = lo_idx + i;
+                float2 v = fetch(idx);
+                float2 r = nco_eval(P.pre_tab, (P.pre_idx0 + (unsigned long long)idx) * P.pre_inc);
+                lds[i] = make_float2(__builtin_fmaf(v.x, r.x, -(v.y * r.y)), __builtin_fmaf(v.x, r.y, v.y * r.x));
             }
         } else {
             for (int i = threadIdx.x; i < count; i += T) lds[i] = fetch(lo_idx + i);

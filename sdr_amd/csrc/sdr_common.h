@@ -37,6 +37,9 @@ struct FrontParams {
     long long nout;         // demod outputs per capture in this call
     long long in0;          // input index of output 0's newest sample
     int hist_len;
+    unsigned long long pre_inc;   // !=0: rotate every INPUT sample by nco64(pre_idx0+idx) while staging (xlating with taps=[1] ahead of the FIR)
+    unsigned long long pre_idx0;  // absolute index of x[0]
+    const float2* pre_tab;
     int vec_ok;             // x is 16-B aligned and stride is even: 16-B direct-to-LDS staging allowed
     int D;
     int ntaps;

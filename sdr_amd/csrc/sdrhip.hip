@@ -61,6 +61,10 @@ struct sdr_handle {
     long long raw_n = 0;
     bool stream_started = false;
 
+    // internal modes used by the FM chain (fm_host.h)
+    bool prerotate = false;   // center_freq applies to the INPUT samples (xlating taps=[1] then FIR)
+    bool skip_slice = false;  // demod floats only: no slicer, no back end
+
     // last call
     int last_ncap = 0;
     long long last_nb = 0, last_nout = 0, last_bits_off = 0;
@@ -246,7 +250,7 @@ static int upload_taps(sdr_handle* h)
     const int n = h->ntaps;
     const double fc = h->cfg.center_freq, fs = h->cfg.sample_rate;
     std::vector<float> rt;
-    if (fc != 0.0) {
+    if (fc != 0.0 && !h->prerotate) {
         // freq_xlating_fir_filter: ctaps[k] = taps[k] * exp(j k 2 pi fc/fs)
         h->rt_complex = true;
         rt.resize(2 * n);
@@ -281,7 +285,7 @@ static int upload_taps(sdr_handle* h)
     h->d_rtaps = nullptr;
     HIPCHK(h, dev_alloc((void**)&h->d_rtaps, rt.size() * sizeof(float)));
     HIPCHK(h, hipMemcpy(h->d_rtaps, rt.data(), rt.size() * sizeof(float), hipMemcpyHostToDevice));
-    h->nco_inc = (fc != 0.0) ? host_nco_inc(fc, fs, h->cfg.decim) : 0;
+    h->nco_inc = (fc != 0.0) ? host_nco_inc(fc, fs, h->prerotate ? 1 : h->cfg.decim) : 0;
     // streaming history: ntaps-1 + 2*D samples (previous output for QUAD, GR's
     // "emit once D items are consumed" rule)
     h->hist_len = n - 1 + 2 * h->cfg.decim;
@@ -543,13 +547,18 @@ static int launch_front_and_back(sdr_handle* h, const float2* x, long long strid
         P.rtaps = h->d_rtaps;
         P.nco_inc = h->nco_inc;
         P.nco_m0 = h->out_count;
-        P.nco_tab = (c.center_freq != 0.0) ? h->d_nco_tab : nullptr;
+        P.nco_tab = (c.center_freq != 0.0 && !h->prerotate) ? h->d_nco_tab : nullptr;
+        if (c.center_freq != 0.0 && h->prerotate) {
+            P.pre_tab = h->d_nco_tab;
+            P.pre_inc = h->nco_inc;
+            P.pre_idx0 = h->in_count;
+        }
         P.atan_tab = h->d_atan_tab;
         P.demod = c.demod;
         P.gain = post ? 1.0f : c.demod_gain;
         P.lo = c.thr_lo;
         P.hi = c.thr_hi;
-        P.do_slice = (c.demod != SDR_DEMOD_NONE && !post) ? 1 : 0;
+        P.do_slice = (c.demod != SDR_DEMOD_NONE && !post && !h->skip_slice) ? 1 : 0;
         P.keep_n = c.keep_n;
         P.keep_c0 = g.keep_c0;
         P.bits = h->d_bits + patch_off;
@@ -597,7 +606,7 @@ static int launch_front_and_back(sdr_handle* h, const float2* x, long long strid
         if (g.nout <= 0) HIPCHK(h, hipEventRecord(h->pev[3 * (h->pcount % SDR_PROF_RING)], h->stream));
         HIPCHK(h, hipEventRecord(h->pev[3 * (h->pcount % SDR_PROF_RING) + 1], h->stream));
     }
-    if (c.demod == SDR_DEMOD_NONE) {
+    if (c.demod == SDR_DEMOD_NONE || h->skip_slice) {
         if (h->profile) {
             HIPCHK(h, hipEventRecord(h->pev[3 * (h->pcount % SDR_PROF_RING) + 2], h->stream));
             h->pcount++;
