@@ -192,8 +192,18 @@ extern "C" int sdr_fm_process(sdr_fm* h, const void* iq, size_t n, int is_dev, s
                            h->d_ataps, h->n_ataps, D, h->d_a2);
         FMCHK(h, hipGetLastError());
     }
-    hipLaunchKernelGGL(k_deemph, dim3(1), dim3(DEEMPH_THREADS), 0, h->stream, h->d_a2, h->n2, h->b0, h->p1, h->d_a3);
-    FMCHK(h, hipGetLastError());
+    {
+        // warm-up length after which p1^k < 2^-60; fall back to the scan kernel for poles near 1
+        int warm = (h->p1 > 0.0 && h->p1 < 1.0) ? (int)ceil(-60.0 * log(2.0) / log(h->p1)) : 1 << 30;
+        if (warm <= 2048) {
+            long long chunks = (h->n2 + DEEMPH_CHUNK - 1) / DEEMPH_CHUNK;
+            hipLaunchKernelGGL(k_deemph_warm, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, h->stream, h->d_a2,
+                               h->n2, h->b0, h->p1, warm, h->d_a3);
+        } else
+            hipLaunchKernelGGL(k_deemph, dim3(1), dim3(DEEMPH_THREADS), 0, h->stream, h->d_a2, h->n2, h->b0, h->p1,
+                               h->d_a3);
+        FMCHK(h, hipGetLastError());
+    }
     {
         int blocks = (int)((h->n4 + 255) / 256);
         hipLaunchKernelGGL(k_resample_fff, dim3(blocks), dim3(256), 0, h->stream, h->d_a3, h->n2, h->n4, h->d_rtaps,

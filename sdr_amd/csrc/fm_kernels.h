@@ -88,6 +88,33 @@ __global__ void __launch_bounds__(DEEMPH_THREADS) k_deemph(const float* __restri
     }
 }
 
+// Fast path of the same recurrence: the pole p1 < 1 forgets its state, so a
+// thread that starts `warm` samples early from y = 0 reaches the true state to
+// below double rounding (p1^warm < 2^-60) before its own chunk begins.  One
+// thread = DEEMPH_CHUNK outputs; any number of workgroups.
+#define DEEMPH_CHUNK 64
+__global__ void __launch_bounds__(256) k_deemph_warm(const float* __restrict__ x, long long n, double b0, double p1,
+                                                     int warm, float* __restrict__ y)
+{
+    const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long a0 = c * DEEMPH_CHUNK;
+    if (a0 >= n) return;
+    const long long a1 = (a0 + DEEMPH_CHUNK < n) ? a0 + DEEMPH_CHUNK : n;
+    long long i = a0 - warm;
+    if (i < 0) i = 0;
+    double yp = 0.0;
+    double xp = (i > 0) ? (double)x[i - 1] : 0.0;
+    for (; i < a1; ++i) {
+        double xi = (double)x[i];
+        double acc = b0 * xi;
+        acc += b0 * xp;
+        acc += p1 * yp;
+        xp = xi;
+        yp = acc;
+        if (i >= a0) y[i] = (float)acc;
+    }
+}
+
 // rational_resampler_fff: output m = sum_k h[p + k L] x[i - k], p = (m M) mod L,
 // i = (m M) / L; then multiply_const(volume).  Zero history.
 __global__ void __launch_bounds__(256) k_resample_fff(const float* __restrict__ x, long long n_in, long long nout,
