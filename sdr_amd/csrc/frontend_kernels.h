@@ -192,28 +192,95 @@ __global__ void __launch_bounds__(256) k_frontend(FrontParams P)
     bool have_y = (m >= 0 || P.hist != nullptr) && (m < P.nout);
     // m == -1 in streaming mode: previous call's last output, recomputed from history
     float ar = 0.f, ai = 0.f;
+    if (USE_LDS) {
+        // Taps live in VGPRs, one tap per lane per 64-tap chunk (loaded with one
+        // coalesced load, the next chunk prefetched), and are broadcast with
+        // v_readlane: no memory access for taps inside the FIR loop.  All lanes run
+        // the loop (readlane needs the whole wave); lanes without an output are
+        // zeroed afterwards.
+        const float* __restrict__ rt = P.rtaps;
+        const float2* p = lds + lsh + (long long)t * P.D;
+        const int lane = lane_id();
+        const bool cplx = P.taps_complex != 0;
+        float tr = 0.f, ti = 0.f;
+        if (lane < P.ntaps) {
+            if (cplx) {
+                float2 tt = reinterpret_cast<const float2*>(rt)[lane];
+                tr = tt.x;
+                ti = tt.y;
+            } else
+                tr = rt[lane];
+        }
+        for (int c0 = 0; c0 < P.ntaps; c0 += 64) {
+            float ntr = 0.f, nti = 0.f;
+            const int jn = c0 + 64 + lane;
+            if (jn < P.ntaps) {
+                if (cplx) {
+                    float2 tt = reinterpret_cast<const float2*>(rt)[jn];
+                    ntr = tt.x;
+                    nti = tt.y;
+                } else
+                    ntr = rt[jn];
+            }
+            const int lim = (P.ntaps - c0) < 64 ? (P.ntaps - c0) : 64;
+            const float2* pc = p + c0;
+            // hand-unrolled by 8 so that eight ds_read_b64 are in flight per wait
+            auto rl = [](float v, int l) {
+                return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+            };
+            int j = 0;
+            if (cplx) {
+                for (; j + 8 <= lim; j += 8) {
+                    float2 s[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) s[u] = pc[j + u];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const float a = rl(tr, j + u), b = rl(ti, j + u);
+                        ar = __builtin_fmaf(a, s[u].x, ar);
+                        ar = __builtin_fmaf(-b, s[u].y, ar);
+                        ai = __builtin_fmaf(a, s[u].y, ai);
+                        ai = __builtin_fmaf(b, s[u].x, ai);
+                    }
+                }
+                for (; j < lim; ++j) {
+                    const float2 s = pc[j];
+                    const float a = rl(tr, j), b = rl(ti, j);
+                    ar = __builtin_fmaf(a, s.x, ar);
+                    ar = __builtin_fmaf(-b, s.y, ar);
+                    ai = __builtin_fmaf(a, s.y, ai);
+                    ai = __builtin_fmaf(b, s.x, ai);
+                }
+            } else {
+                for (; j + 8 <= lim; j += 8) {
+                    float2 s[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) s[u] = pc[j + u];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const float a = rl(tr, j + u);
+                        ar = __builtin_fmaf(a, s[u].x, ar);
+                        ai = __builtin_fmaf(a, s[u].y, ai);
+                    }
+                }
+                for (; j < lim; ++j) {
+                    const float2 s = pc[j];
+                    const float a = rl(tr, j);
+                    ar = __builtin_fmaf(a, s.x, ar);
+                    ai = __builtin_fmaf(a, s.y, ai);
+                }
+            }
+            tr = ntr;
+            ti = nti;
+        }
+        if (!have_y) {
+            ar = 0.f;
+            ai = 0.f;
+        }
+    }
     if (have_y) {
         const float* __restrict__ rt = P.rtaps;
         if (USE_LDS) {
-            const float2* p = lds + lsh + (long long)t * P.D;
-            if (P.taps_complex) {
-                for (int j = 0; j < P.ntaps; ++j) {
-                    float2 s = p[j];
-                    float tr = rt[2 * j], ti = rt[2 * j + 1];
-                    ar = __builtin_fmaf(tr, s.x, ar);
-                    ar = __builtin_fmaf(-ti, s.y, ar);
-                    ai = __builtin_fmaf(tr, s.y, ai);
-                    ai = __builtin_fmaf(ti, s.x, ai);
-                }
-            } else {
-#pragma unroll 8
-                for (int j = 0; j < P.ntaps; ++j) {
-                    float2 s = p[j];
-                    float tp = rt[j];
-                    ar = __builtin_fmaf(tp, s.x, ar);
-                    ai = __builtin_fmaf(tp, s.y, ai);
-                }
-            }
         } else {
             long long base = lo_idx + (long long)t * P.D;
             for (int j = 0; j < P.ntaps; ++j) {
