@@ -130,6 +130,20 @@ def fm_workload(torch, dev, skip_cpu, n=1 << 24, fs=2.4e6, steps=20):
     return out
 
 
+def pmc_traffic(ncap):
+    """HBM bytes per k_frontend launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
+    on this same command; counters cannot be read from inside the process).  None if the workload differs."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_frontend.json")
+    try:
+        with open(path) as f:
+            rec = json.load(f)
+    except OSError:
+        return None, None
+    if "captures_per_gpu=%d" % ncap not in rec.get("workload", ""):
+        return None, None
+    return int(rec["per_launch"]["hbm_bytes"]), "profiles/r01_pmc_frontend.json"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -225,6 +239,7 @@ def main():
         fk = float(np.mean(front_ms)) if front_ms else float("nan")
         bk = float(np.mean(back_ms)) if back_ms else float("nan")
         achieved = BYTES_PER_SAMPLE * samples_per_step / (fk * 1e-3) / 1e9
+        traffic, traffic_src = pmc_traffic(ncap)
         line = {
             "metric": "IQ Msps through filter+demod+slice+decode (whole job)",
             "value": round(value, 1), "unit": "Msps", "n_gpus": world, "steps": args.steps,
@@ -237,7 +252,7 @@ def main():
                        "parallelism": "captures sharded per GPU, RCCL all_gather of frame records" if world > 1 else "1 GPU"},
             "roofline": {"bound": "hbm", "kernel": "k_frontend<true>", "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": None, "kernel_ms": round(fk, 4), "backend_kernel_ms": round(bk, 4),
+                         "traffic": traffic, "traffic_source": traffic_src, "kernel_ms": round(fk, 4), "backend_kernel_ms": round(bk, 4),
                          "bytes_per_launch": BYTES_PER_SAMPLE * samples_per_step},
             "frames_decoded": len(frames) * world, "verified": "all captures decode to the transmitted packets; 3 captures bit-exact vs oracle",
         }
