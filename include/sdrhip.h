@@ -140,6 +140,17 @@ SDR_API int sdr_destroy(sdr_handle* h);
  * translated as freq_xlating_fir_filter_ccc does. */
 SDR_API int sdr_set_taps(sdr_handle* h, const float* taps, int n, int is_complex);
 SDR_API int sdr_set_post_taps(sdr_handle* h, const float* taps, int n);
+/* analog_pwr_squelch_cc (ramp 0) between the channel filter and the demodulator:
+ * p = alpha*|y|^2 + (1-alpha)*p (double), an item passes iff !(p < 10^(db/10));
+ * gate != 0 drops muted items (the stream gets shorter), gate == 0 zeroes them.
+ * ref: TFA/decoder.grc:391-446, TFA/analyzer.grc:544-599 (alpha 1e-4, -40 dB, gate True).
+ * Resets the squelch state.  Chains with a post-demod filter are not supported. */
+SDR_API int sdr_set_squelch(sdr_handle* h, double threshold_db, double alpha, int gate);
+/* items that passed the squelch in the last call, one int32 per capture.  In a
+ * batch behind a gating squelch sdr_out.n_bits / the row pitch of sdr_fetch_bits
+ * and sdr_fetch_demod are the ungated upper bound; rows are zero (bits) or
+ * undefined (demod floats) beyond the capture's own count. */
+SDR_API int sdr_fetch_squelch_counts(sdr_handle* h, int32_t* out, size_t cap, size_t* n);
 /* run on a caller-owned HIP stream (hipStream_t as void*), e.g. torch's
  * current stream; NULL = the handle's own stream. */
 SDR_API int sdr_set_stream(sdr_handle* h, void* hip_stream);

@@ -14,6 +14,7 @@ _LIB = None
 WIN_HAMMING, WIN_HANN, WIN_BLACKMAN, WIN_RECTANGULAR, WIN_KAISER, WIN_BLACKMAN_HARRIS = range(6)
 
 _f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+_f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
 _i8p = np.ctypeslib.ndpointer(np.int8, flags="C_CONTIGUOUS")
 
 
@@ -59,7 +60,7 @@ def lib():
         L.orc_iir_deemph.argtypes = [_f32p, C.c_int64, C.c_double, C.c_double,
                                      np.ctypeslib.ndpointer(np.float64), _f32p]
         L.orc_pwr_squelch.restype = C.c_int64
-        L.orc_pwr_squelch.argtypes = [_f32p, C.c_int64, C.c_double, C.c_double, C.c_int, _f32p, _f32p]
+        L.orc_pwr_squelch.argtypes = [_f32p, C.c_int64, C.c_double, C.c_double, C.c_int, _f64p, _f32p]
         L.orc_slice.restype = C.c_int64
         L.orc_slice.argtypes = [_f32p, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_int,
                                 C.POINTER(C.c_int), C.POINTER(C.c_int), _i8p]
@@ -224,10 +225,11 @@ def fm_deemph(x, fs, tau=75e-6, state=None):
     return y
 
 
-def pwr_squelch(x, db, alpha, gate=True):
+def pwr_squelch(x, db, alpha, gate=True, state=None):
+    """analog_pwr_squelch_cc, ramp 0 (a7).  state: float64[1] power carried between calls."""
     xf = _c2f(x)
     y = np.zeros_like(xf)
-    st = np.zeros(1, np.float32)
+    st = np.zeros(1, np.float64) if state is None else state
     k = lib().orc_pwr_squelch(xf, xf.size // 2, db, alpha, int(gate), st, y)
     return y[:2 * k].view(np.complex64)
 

@@ -409,18 +409,25 @@ ORC_API void orc_iir_deemph(const float* x, int64_t n, double b0, double p1, dou
     state[1] = yp;
 }
 
-/* gr-analog/lib/pwr_squelch_cc_impl.cc + squelch_base_cc_impl.cc with ramp=0:
- * single-pole IIR power estimate, gate=True drops muted items.
- * TFA/decoder.grc:391-446 (-40 dB, alpha 1e-4).  Returns #items written. */
+/* ------------------------------------------------- pwr_squelch_cc (row a7)
+ * gr-analog/lib/pwr_squelch_cc_impl.{h,cc} + squelch_base_cc_impl.cc (3.7.11),
+ * ramp = 0: d_pwr = d_iir.filter(re*re + im*im) with
+ * filter::single_pole_iir<double,double,double> (y = alpha*x + (1-alpha)*y_prev
+ * in double, y_prev starts at 0), the magnitude itself in float; mute() is
+ * d_pwr < d_threshold with d_threshold = pow(10, db/10) (double).  gate: muted
+ * items are dropped, otherwise zeroed.  TFA/decoder.grc:391-446 (alpha 1e-4,
+ * -40 dB, gate True).  state[0] = d_pwr carried between calls.
+ * Returns #items written. */
 ORC_API int64_t orc_pwr_squelch(const float* x, int64_t n, double db, double alpha, int gate,
-                                float* state /* {power} */, float* y)
+                                double* state /* {power} */, float* y)
 {
-    float thr = (float)pow(10.0, db / 10.0);
-    float a = (float)alpha, oma = 1.0f - (float)alpha, p = state[0];
+    const double thr = pow(10.0, db / 10.0);
+    const double a = alpha, oma = 1.0 - alpha;
+    double p = state[0];
     int64_t k = 0;
     for (int64_t i = 0; i < n; i++) {
-        float m2 = fmaf(x[2 * i], x[2 * i], x[2 * i + 1] * x[2 * i + 1]);
-        p = fmaf(a, m2, oma * p);
+        float m2 = x[2 * i] * x[2 * i] + x[2 * i + 1] * x[2 * i + 1];
+        p = a * (double)m2 + oma * p;
         int mute = p < thr;
         if (!mute) {
             y[2 * k] = x[2 * i];

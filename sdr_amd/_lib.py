@@ -120,7 +120,8 @@ EXPORTS = [
     "sdr_set_post_taps", "sdr_set_stream", "sdr_synchronize", "sdr_last_error", "sdr_process_iq",
     "sdr_process_bits", "sdr_batch_process", "sdr_fetch_frames", "sdr_fetch_bits", "sdr_fetch_demod",
     "sdr_decoder_state", "sdr_timer_start", "sdr_timer_stop", "sdr_timer_elapsed_ms", "sdr_version",
-    "sdr_profile_enable", "sdr_profile_read", "sdr_export_frames",
+    "sdr_profile_enable", "sdr_profile_read", "sdr_export_frames", "sdr_set_squelch",
+    "sdr_fetch_squelch_counts",
     "sdr_fm_create", "sdr_fm_destroy", "sdr_fm_set_stream", "sdr_fm_process", "sdr_fm_fetch",
     "sdr_fm_last_error",
 ]
@@ -151,6 +152,10 @@ def load():
     L.sdr_set_taps.argtypes = [H, fp, C.c_int, C.c_int]
     L.sdr_set_post_taps.restype = C.c_int
     L.sdr_set_post_taps.argtypes = [H, fp, C.c_int]
+    L.sdr_set_squelch.restype = C.c_int
+    L.sdr_set_squelch.argtypes = [H, C.c_double, C.c_double, C.c_int]
+    L.sdr_fetch_squelch_counts.restype = C.c_int
+    L.sdr_fetch_squelch_counts.argtypes = [H, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.sdr_set_stream.restype = C.c_int
     L.sdr_set_stream.argtypes = [H, C.c_void_p]
     L.sdr_synchronize.restype = C.c_int

@@ -43,7 +43,9 @@ def _is_torch(x):
 class Chain(object):
     def __init__(self, sample_rate, decim=1, center_freq=0.0, taps=None, demod=DEMOD_MAG2, demod_gain=1.0,
                  thr=(0.05, 0.15), thr_init=0, keep_n=1, decoder=DEC_NONE, decoder_rate=0.0, post_taps=None,
-                 tap_demod=False, max_batch=1, max_frames=16, max_samples=1 << 20):
+                 tap_demod=False, max_batch=1, max_frames=16, max_samples=1 << 20, squelch=None):
+        """squelch=(threshold_db, alpha[, gate=True]): analog_pwr_squelch_cc between the channel
+        filter and the demodulator (TFA/decoder.grc:391-446)."""
         self._L = _lib.load()
         self._h = C.c_void_p()
         cfg = _lib.ChainCfg()
@@ -73,6 +75,21 @@ class Chain(object):
             pt = np.ascontiguousarray(post_taps, np.float32)
             _lib.check(self._h, self._L.sdr_set_post_taps(self._h, pt.ctypes.data_as(C.POINTER(C.c_float)), pt.size))
         self.out = _lib.Out()
+        if squelch is not None:
+            self.set_squelch(*squelch)
+
+    def set_squelch(self, threshold_db, alpha, gate=True):
+        _lib.check(self._h, self._L.sdr_set_squelch(self._h, float(threshold_db), float(alpha), int(bool(gate))))
+
+    def fetch_squelch_counts(self):
+        """Items that passed the squelch in the last call, per capture."""
+        n = C.c_size_t()
+        _lib.check(self._h, self._L.sdr_fetch_squelch_counts(self._h, None, 0, C.byref(n)))
+        out = np.zeros(n.value, np.int32)
+        if n.value:
+            _lib.check(self._h, self._L.sdr_fetch_squelch_counts(self._h, C.c_void_p(out.ctypes.data), out.size,
+                                                                 C.byref(n)))
+        return out
 
     # -- life cycle
     def close(self):

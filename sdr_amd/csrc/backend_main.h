@@ -32,6 +32,15 @@ __global__ void __launch_bounds__(BK_THREADS) k_backend(BackParams P)
     const int cap = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     int8_t* bits = P.bits + (long long)cap * P.bits_stride;
     DecState* st = P.st + cap;
+    // behind a gating squelch every capture of a batch has its own length
+    long long nout = P.nout, nb = P.nb;
+    int run_decoder = P.run_decoder;
+    if (P.nout_var) {
+        nout = P.nout_var[cap];
+        nb = P.patch_off + (nout > P.keep_c0 ? (nout - P.keep_c0 + P.keep_n - 1) / P.keep_n : 0);
+        if (P.decoder >= SDR_DEC_TS33C && P.decoder <= SDR_DEC_TFA_GRC)
+            run_decoder = ((double)nb * 1e6 / P.dec_rate > (P.decoder == SDR_DEC_TS33C ? 1550.0 : 500.0)) ? 1 : 0;
+    }
 
     if (tid == 0) {
         if (P.fresh) {
@@ -81,7 +90,7 @@ __global__ void __launch_bounds__(BK_THREADS) k_backend(BackParams P)
         int8_t* wbits = bits + P.patch_off;
         for (int i = t0; i < t1; ++i) {
             long long o_beg = (long long)i * P.tile_out;
-            long long o_end = o_beg + P.tile_out < P.nout ? o_beg + P.tile_out : P.nout;
+            long long o_end = o_beg + P.tile_out < nout ? o_beg + P.tile_out : nout;
             long long fe = ts[i].first_evt;
             if (carry == 1) {
                 long long e = fe >= 0 ? fe : o_end;
@@ -101,11 +110,10 @@ __global__ void __launch_bounds__(BK_THREADS) k_backend(BackParams P)
         __syncthreads();
         if (tid == 0) st->thr_state = s_cnt[0];
     }
-    if (!P.run_decoder || P.decoder == SDR_DEC_NONE) return;
+    if (!run_decoder || P.decoder == SDR_DEC_NONE) return;
     __syncthreads();
 
     // ---- phase 1: run-length ------------------------------------------------
-    const long long nb = P.nb;
     int32_t* pos = P.runs + (long long)cap * (P.runs_cap + 2);
     const bool b_in_lds = nb <= BK_BYTES_LDS && ((reinterpret_cast<uintptr_t>(bits) & 15) == 0);
     if (b_in_lds) {

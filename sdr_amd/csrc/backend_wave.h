@@ -250,7 +250,7 @@ __device__ inline void wave_stream_decode(const BackParams& P, int cap, WF W, co
     const int lane = threadIdx.x & 63;
     const bool ts33c = (P.decoder == SDR_DEC_TS33C);
     const double reset_limit = ts33c ? 1550.0 : 500.0;
-    if (!(P.nb > 0 && (any_one || st->n_cur > 0))) {
+    if (!(R > 0 && (any_one || st->n_cur > 0))) {
         st->state = 0;
         return;
     }

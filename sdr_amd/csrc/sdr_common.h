@@ -81,6 +81,47 @@ struct PostParams {         // real FIR on demodulated floats + slicer (TFA/anal
     int tile_out;
 };
 
+// pwr_squelch_cc state carried between streaming calls (row a7)
+struct SquelchState {
+    double p;           // single-pole IIR power estimate
+    float2 last;        // last item that passed (quadrature_demod history after the gate)
+    int32_t near_hits;  // calls in which the exact sequential re-run was taken
+    int32_t pad_;
+};
+
+struct SquelchParams {
+    const float2* y;    // channel-filter output, n items per capture
+    long long y_stride;
+    long long n;
+    double alpha, thr;
+    int gate;
+    int fresh;          // batch: every capture starts from p = 0, last = 0
+    float2* z;          // passed items; z[-1] is a valid slot (history item for the demodulator)
+    long long z_stride;
+    int32_t* cnt;       // items written per capture
+    SquelchState* st;
+};
+
+struct DemodParams {    // demod + gain + slicer on the gated stream (ragged: cnt[cap] items)
+    const float2* z;
+    long long z_stride;
+    const int32_t* cnt;
+    long long nmax;     // grid extent in items; bits beyond cnt are zero-filled up to here
+    const float* atan_tab;
+    int demod;
+    float gain, lo, hi;
+    int do_slice;
+    int keep_n;
+    long long keep_c0;
+    int8_t* bits;
+    long long bits_stride;
+    float* tap;
+    long long tap_stride;
+    TileSum* tsum;
+    int tiles_per_capture;
+    int tile_out;
+};
+
 struct BackParams {
     int8_t* bits;           // per capture bits_stride bytes
     long long bits_stride;
@@ -89,6 +130,7 @@ struct BackParams {
     int tiles_per_capture;
     int tile_out;
     long long nout;         // demod outputs this call (for the last tile's extent)
+    const int32_t* nout_var;// batch behind a gating squelch: per-capture nout; nb and run_decoder are then derived per capture
     int keep_n;
     long long keep_c0;
     long long patch_off;    // byte offset inside the capture's bits where this call's output starts (streaming append)

@@ -14,6 +14,7 @@
 #include "backend_kernels.h"
 #include "backend_main.h"
 #include "fm_kernels.h"
+#include "squelch_kernels.h"
 
 #ifndef M_PI
 #define M_PI 3.14159265358979323846
@@ -61,6 +62,16 @@ struct sdr_handle {
     long long keep_ctr = 1;
     long long raw_n = 0;
     bool stream_started = false;
+
+    // pwr_squelch_cc between channel filter and demodulator (sdr_set_squelch)
+    bool squelch_on = false;
+    int sq_gate = 1;
+    double sq_alpha = 0, sq_thr = 0;
+    float2* d_sq_y = nullptr;     // channel-filter output
+    float2* d_sq_z = nullptr;     // gated items (+1 leading history slot per capture)
+    long long sq_stride = 0;
+    int32_t* d_sq_cnt = nullptr;
+    SquelchState* d_sq_st = nullptr;
 
     // internal modes used by the FM chain (fm_host.h)
     bool prerotate = false;   // center_freq applies to the INPUT samples (xlating taps=[1] then FIR)
@@ -339,7 +350,7 @@ extern "C" int sdr_destroy(sdr_handle* h)
     if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
     void* ptrs[] = {h->d_rtaps, h->d_post_rtaps, h->d_nco_tab, h->d_atan_tab, h->d_pow, h->d_log2, h->d_iq,
                     h->d_hist[0], h->d_hist[1], h->d_bits, h->d_tap, h->d_tap2, h->d_tsum, h->d_runs,
-                    h->d_cur, h->d_st, h->d_frames};
+                    h->d_cur, h->d_st, h->d_frames, h->d_sq_y, h->d_sq_z, h->d_sq_cnt, h->d_sq_st};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (hipEvent_t e : h->pev) (void)hipEventDestroy(e);
@@ -468,6 +479,30 @@ extern "C" int sdr_set_post_taps(sdr_handle* h, const float* taps, int n)
     return SDR_OK;
 }
 
+extern "C" int sdr_set_squelch(sdr_handle* h, double threshold_db, double alpha, int gate)
+{
+    if (!h || !(alpha > 0.0) || alpha > 1.0) return fail(h, SDR_E_ARG, "sdr_set_squelch: alpha must be in (0, 1]");
+    if (h->cfg.post_ntaps > 0 || h->cfg.demod == SDR_DEMOD_NONE || h->prerotate || h->skip_slice)
+        return fail(h, SDR_E_ARG, "sdr_set_squelch: needs a MAG2/QUAD chain without a post-demod filter");
+    (void)hipSetDevice(h->device);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const long long B = h->cfg.max_batch;
+    if (!h->d_sq_y) {
+        h->sq_stride = (long long)(h->cfg.max_samples / h->cfg.decim) + 4;
+        HIPCHK(h, dev_alloc((void**)&h->d_sq_y, (size_t)(B * h->sq_stride) * sizeof(float2)));
+        HIPCHK(h, dev_alloc((void**)&h->d_sq_z, (size_t)(B * h->sq_stride) * sizeof(float2)));
+        HIPCHK(h, dev_alloc((void**)&h->d_sq_cnt, (size_t)B * sizeof(int32_t)));
+        HIPCHK(h, dev_alloc((void**)&h->d_sq_st, (size_t)B * sizeof(SquelchState)));
+    }
+    HIPCHK(h, hipMemset(h->d_sq_st, 0, (size_t)B * sizeof(SquelchState)));
+    HIPCHK(h, hipMemset(h->d_sq_cnt, 0, (size_t)B * sizeof(int32_t)));
+    h->sq_alpha = alpha;
+    h->sq_thr = std::pow(10.0, threshold_db / 10.0);
+    h->sq_gate = gate ? 1 : 0;
+    h->squelch_on = true;
+    return SDR_OK;
+}
+
 extern "C" int sdr_set_stream(sdr_handle* h, void* s)
 {
     if (!h) return SDR_E_ARG;
@@ -524,6 +559,118 @@ struct CallGeom {
     bool use_lds;
 };
 
+// channel filter (+ demod + slicer unless the output goes to the squelch stage)
+static int launch_front(sdr_handle* h, const float2* x, long long stride, long long n, int ncap,
+                        const float2* hist, int hist_len, const CallGeom& g, long long patch_off, bool to_squelch)
+{
+    const sdr_chain_cfg& c = h->cfg;
+    const bool post = c.post_ntaps > 0;
+    FrontParams P;
+    memset(&P, 0, sizeof P);
+    P.x = x;
+    P.hist = hist;
+    P.stride = stride;
+    P.n = n;
+    P.nout = g.nout;
+    P.in0 = g.in0;
+    P.hist_len = hist_len;
+    P.vec_ok = ((((uintptr_t)x) & 15) == 0 && (stride % 2) == 0) ? 1 : 0;
+    P.D = c.decim;
+    P.ntaps = h->ntaps;
+    P.taps_complex = h->rt_complex;
+    P.rtaps = h->d_rtaps;
+    P.nco_inc = h->nco_inc;
+    P.nco_m0 = h->out_count;
+    P.nco_tab = (c.center_freq != 0.0 && !h->prerotate) ? h->d_nco_tab : nullptr;
+    if (c.center_freq != 0.0 && h->prerotate) {
+        P.pre_tab = h->d_nco_tab;
+        P.pre_inc = h->nco_inc;
+        P.pre_idx0 = h->in_count;
+    }
+    P.atan_tab = h->d_atan_tab;
+    P.demod = c.demod;
+    P.gain = post ? 1.0f : c.demod_gain;
+    P.lo = c.thr_lo;
+    P.hi = c.thr_hi;
+    P.do_slice = (c.demod != SDR_DEMOD_NONE && !post && !h->skip_slice) ? 1 : 0;
+    P.keep_n = c.keep_n;
+    P.keep_c0 = g.keep_c0;
+    P.bits = h->d_bits + patch_off;
+    P.bits_stride = h->bits_stride;
+    P.tap = (c.tap_demod || post || c.demod == SDR_DEMOD_NONE) ? h->d_tap : nullptr;
+    P.tap_stride = h->tap_stride;
+    P.tsum = h->d_tsum;
+    P.tiles_per_capture = g.tiles;
+    P.tile_out = g.tile_out;
+    if (to_squelch) {
+        P.demod = SDR_DEMOD_NONE;
+        P.do_slice = 0;
+        P.tap = reinterpret_cast<float*>(h->d_sq_y);
+        P.tap_stride = 2 * h->sq_stride;
+    } else if (c.demod == SDR_DEMOD_NONE && !h->d_tap)
+        return fail(h, SDR_E_ARG, "demod NONE needs cfg.tap_demod (complex output buffer)");
+    dim3 grid(g.tiles, ncap), block(g.T);
+    if (g.use_lds)
+        hipLaunchKernelGGL(k_frontend<true>, grid, block, g.lds, h->stream, P);
+    else
+        hipLaunchKernelGGL(k_frontend<false>, grid, block, 0, h->stream, P);
+    HIPCHK(h, hipGetLastError());
+    if (post && !to_squelch) {
+        PostParams Q;
+        memset(&Q, 0, sizeof Q);
+        Q.v = h->d_tap;
+        Q.v_stride = h->tap_stride;
+        Q.nout = g.nout;
+        Q.ntaps = c.post_ntaps;
+        Q.rtaps = h->d_post_rtaps;
+        Q.gain = c.demod_gain;
+        Q.lo = c.thr_lo;
+        Q.hi = c.thr_hi;
+        Q.keep_n = c.keep_n;
+        Q.keep_c0 = g.keep_c0;
+        Q.bits = h->d_bits + patch_off;
+        Q.bits_stride = h->bits_stride;
+        Q.tap = h->d_tap2;
+        Q.tap_stride = h->tap_stride;
+        Q.tsum = h->d_tsum;
+        Q.tiles_per_capture = g.tiles;
+        Q.tile_out = g.tile_out;
+        size_t lds = (size_t)(g.T + c.post_ntaps) * sizeof(float);
+        hipLaunchKernelGGL(k_post_fir_slice, grid, block, lds, h->stream, Q);
+        HIPCHK(h, hipGetLastError());
+    }
+    return SDR_OK;
+}
+
+// squelch stage: channel filter -> complex items -> k_squelch -> gated items + per-capture counts
+static int launch_squelch_stage(sdr_handle* h, const float2* x, long long stride, long long n, int ncap,
+                                const float2* hist, int hist_len, const CallGeom& g, int fresh)
+{
+    if (g.nout > h->sq_stride - 2) return fail(h, SDR_E_CAPACITY, "squelch buffer too small");
+    if (g.nout > 0) {
+        int r = launch_front(h, x, stride, n, ncap, hist, hist_len, g, 0, true);
+        if (r) return r;
+    }
+    SquelchParams S;
+    memset(&S, 0, sizeof S);
+    S.y = h->d_sq_y;
+    S.y_stride = h->sq_stride;
+    S.n = g.nout;
+    S.alpha = h->sq_alpha;
+    S.thr = h->sq_thr;
+    S.gate = h->sq_gate;
+    S.fresh = fresh;
+    S.z = h->d_sq_z + 1;
+    S.z_stride = h->sq_stride;
+    S.cnt = h->d_sq_cnt;
+    S.st = h->d_sq_st;
+    hipLaunchKernelGGL(k_squelch, dim3(ncap), dim3(SQ_THREADS), 0, h->stream, S);
+    HIPCHK(h, hipGetLastError());
+    return SDR_OK;
+}
+
+// With the squelch enabled the caller has run launch_squelch_stage first and g
+// describes the gated stream (g.nout = item count, or its upper bound in a batch).
 static int launch_front_and_back(sdr_handle* h, const float2* x, long long stride, long long n, int ncap,
                                  const float2* hist, int hist_len, const CallGeom& g, long long patch_off,
                                  long long nb_total, int fresh, int use_state_thr, int run_decoder)
@@ -533,82 +680,36 @@ static int launch_front_and_back(sdr_handle* h, const float2* x, long long strid
     if (post && (int)h->post_taps.size() != c.post_ntaps)
         return fail(h, SDR_E_ARG, "post-demod filter configured but sdr_set_post_taps not called");
     if (g.tiles > h->tsum_stride) return fail(h, SDR_E_CAPACITY, "tile table too small");
-    if (g.nout > 0) {
-        FrontParams P;
-        memset(&P, 0, sizeof P);
-        P.x = x;
-        P.hist = hist;
-        P.stride = stride;
-        P.n = n;
-        P.nout = g.nout;
-        P.in0 = g.in0;
-        P.hist_len = hist_len;
-        P.vec_ok = ((((uintptr_t)x) & 15) == 0 && (stride % 2) == 0) ? 1 : 0;
-        P.D = c.decim;
-        P.ntaps = h->ntaps;
-        P.taps_complex = h->rt_complex;
-        P.rtaps = h->d_rtaps;
-        P.nco_inc = h->nco_inc;
-        P.nco_m0 = h->out_count;
-        P.nco_tab = (c.center_freq != 0.0 && !h->prerotate) ? h->d_nco_tab : nullptr;
-        if (c.center_freq != 0.0 && h->prerotate) {
-            P.pre_tab = h->d_nco_tab;
-            P.pre_inc = h->nco_inc;
-            P.pre_idx0 = h->in_count;
-        }
-        P.atan_tab = h->d_atan_tab;
-        P.demod = c.demod;
-        P.gain = post ? 1.0f : c.demod_gain;
-        P.lo = c.thr_lo;
-        P.hi = c.thr_hi;
-        P.do_slice = (c.demod != SDR_DEMOD_NONE && !post && !h->skip_slice) ? 1 : 0;
-        P.keep_n = c.keep_n;
-        P.keep_c0 = g.keep_c0;
-        P.bits = h->d_bits + patch_off;
-        P.bits_stride = h->bits_stride;
-        P.tap = (c.tap_demod || post || c.demod == SDR_DEMOD_NONE) ? h->d_tap : nullptr;
-        P.tap_stride = h->tap_stride;
-        P.tsum = h->d_tsum;
-        P.tiles_per_capture = g.tiles;
-        P.tile_out = g.tile_out;
-        if (c.demod == SDR_DEMOD_NONE && !h->d_tap)
-            return fail(h, SDR_E_ARG, "demod NONE needs cfg.tap_demod (complex output buffer)");
-        dim3 grid(g.tiles, ncap), block(g.T);
-        if (h->profile) HIPCHK(h, hipEventRecord(h->pev[3 * (h->pcount % SDR_PROF_RING)], h->stream));
-        if (g.use_lds)
-            hipLaunchKernelGGL(k_frontend<true>, grid, block, g.lds, h->stream, P);
-        else
-            hipLaunchKernelGGL(k_frontend<false>, grid, block, 0, h->stream, P);
+    if (h->profile) HIPCHK(h, hipEventRecord(h->pev[3 * (h->pcount % SDR_PROF_RING)], h->stream));
+    if (g.nout > 0 && !h->squelch_on) {
+        int r = launch_front(h, x, stride, n, ncap, hist, hist_len, g, patch_off, false);
+        if (r) return r;
+    } else if (g.nout > 0) {
+        DemodParams Q;
+        memset(&Q, 0, sizeof Q);
+        Q.z = h->d_sq_z + 1;
+        Q.z_stride = h->sq_stride;
+        Q.cnt = h->d_sq_cnt;
+        Q.nmax = g.nout;
+        Q.atan_tab = h->d_atan_tab;
+        Q.demod = c.demod;
+        Q.gain = c.demod_gain;
+        Q.lo = c.thr_lo;
+        Q.hi = c.thr_hi;
+        Q.do_slice = 1;
+        Q.keep_n = c.keep_n;
+        Q.keep_c0 = g.keep_c0;
+        Q.bits = h->d_bits + patch_off;
+        Q.bits_stride = h->bits_stride;
+        Q.tap = c.tap_demod ? h->d_tap : nullptr;
+        Q.tap_stride = h->tap_stride;
+        Q.tsum = h->d_tsum;
+        Q.tiles_per_capture = g.tiles;
+        Q.tile_out = g.tile_out;
+        hipLaunchKernelGGL(k_demod_slice, dim3(g.tiles, ncap), dim3(g.T), 0, h->stream, Q);
         HIPCHK(h, hipGetLastError());
-        if (post) {
-            PostParams Q;
-            memset(&Q, 0, sizeof Q);
-            Q.v = h->d_tap;
-            Q.v_stride = h->tap_stride;
-            Q.nout = g.nout;
-            Q.ntaps = c.post_ntaps;
-            Q.rtaps = h->d_post_rtaps;
-            Q.gain = c.demod_gain;
-            Q.lo = c.thr_lo;
-            Q.hi = c.thr_hi;
-            Q.keep_n = c.keep_n;
-            Q.keep_c0 = g.keep_c0;
-            Q.bits = h->d_bits + patch_off;
-            Q.bits_stride = h->bits_stride;
-            Q.tap = h->d_tap2;
-            Q.tap_stride = h->tap_stride;
-            Q.tsum = h->d_tsum;
-            Q.tiles_per_capture = g.tiles;
-            Q.tile_out = g.tile_out;
-            size_t lds = (size_t)(g.T + c.post_ntaps) * sizeof(float);
-            hipLaunchKernelGGL(k_post_fir_slice, grid, block, lds, h->stream, Q);
-            HIPCHK(h, hipGetLastError());
-        }
     }
-    if (h->profile) {
-        if (g.nout <= 0) HIPCHK(h, hipEventRecord(h->pev[3 * (h->pcount % SDR_PROF_RING)], h->stream));
-        HIPCHK(h, hipEventRecord(h->pev[3 * (h->pcount % SDR_PROF_RING) + 1], h->stream));
-    }
+    if (h->profile) HIPCHK(h, hipEventRecord(h->pev[3 * (h->pcount % SDR_PROF_RING) + 1], h->stream));
     if (c.demod == SDR_DEMOD_NONE || h->skip_slice) {
         if (h->profile) {
             HIPCHK(h, hipEventRecord(h->pev[3 * (h->pcount % SDR_PROF_RING) + 2], h->stream));
@@ -625,6 +726,7 @@ static int launch_front_and_back(sdr_handle* h, const float2* x, long long strid
     Bp.tiles_per_capture = g.tiles;
     Bp.tile_out = g.tile_out;
     Bp.nout = g.nout;
+    Bp.nout_var = (h->squelch_on && fresh) ? h->d_sq_cnt : nullptr;
     Bp.keep_n = c.keep_n;
     Bp.keep_c0 = g.keep_c0;
     Bp.patch_off = patch_off;
@@ -651,29 +753,31 @@ static int launch_front_and_back(sdr_handle* h, const float2* x, long long strid
     return SDR_OK;
 }
 
-static void fill_geom(const sdr_handle* h, long long nout, long long in0, long long keep_c0, CallGeom& g)
+static void fill_geom(const sdr_handle* h, long long nout, long long in0, long long keep_c0, CallGeom& g,
+                      bool to_squelch = false)
 {
     g.nout = nout;
     g.in0 = in0;
     g.keep_c0 = keep_c0;
     const long long kn = h->cfg.keep_n;
     g.ne = nout > keep_c0 ? (nout - keep_c0 + kn - 1) / kn : 0;
-    if (h->cfg.post_ntaps > 0) {
-        // the post-filter kernel uses the same tiling; one output per thread
-        g.T = 256;
-        g.lds = 0;
-        g.use_lds = true;
-        int T;
-        size_t lds;
-        bool ul;
-        pick_tile(h, T, lds, ul);
-        g.T = T;
-        g.lds = lds;
-        g.use_lds = ul;
-    } else
-        pick_tile(h, g.T, g.lds, g.use_lds);
-    g.tile_out = g.T - (h->cfg.demod == SDR_DEMOD_QUAD ? 1 : 0);
+    pick_tile(h, g.T, g.lds, g.use_lds);
+    g.tile_out = g.T - ((h->cfg.demod == SDR_DEMOD_QUAD && !to_squelch) ? 1 : 0);
     g.tiles = (int)((nout + g.tile_out - 1) / g.tile_out);
+}
+
+// geometry of k_demod_slice on the gated stream (one item per thread)
+static void fill_geom_gated(const sdr_handle* h, long long nitems, long long keep_c0, CallGeom& g)
+{
+    memset(&g, 0, sizeof g);
+    g.nout = nitems;
+    g.keep_c0 = keep_c0;
+    const long long kn = h->cfg.keep_n;
+    g.ne = nitems > keep_c0 ? (nitems - keep_c0 + kn - 1) / kn : 0;
+    g.T = 256;
+    g.tile_out = 256;
+    g.tiles = (int)((nitems + 255) / 256);
+    g.use_lds = true;
 }
 
 static int finish_out(sdr_handle* h, sdr_out* out, unsigned long long n_in, long long nbits)
@@ -706,13 +810,21 @@ extern "C" int sdr_batch_process(sdr_handle* h, const void* iq, size_t n, size_t
     const sdr_chain_cfg& c = h->cfg;
     CallGeom g;
     // gr::sync_decimator: a finite capture of n items yields n/D outputs
-    fill_geom(h, (long long)(n / c.decim), 0, c.keep_n - 1, g);
+    fill_geom(h, (long long)(n / c.decim), 0, c.keep_n - 1, g, h->squelch_on);
     unsigned long long saved = h->out_count;
     h->out_count = 0;  // every capture starts at NCO phase 0
+    int r = SDR_OK;
+    if (h->squelch_on) {
+        // gated stream: per-capture lengths stay on the device (BackParams.nout_var);
+        // g becomes the upper-bound geometry of the demod stage
+        r = launch_squelch_stage(h, x, (long long)stride, (long long)n, ncap, nullptr, 0, g, 1);
+        fill_geom_gated(h, (long long)(n / c.decim), c.keep_n - 1, g);
+    }
     int run = 1;
     if (is_stream_decoder(c.decoder))
         run = ((double)g.ne * 1e6 / h->dec_rate > decoder_reset_limit(c.decoder)) ? 1 : 0;
-    int r = launch_front_and_back(h, x, (long long)stride, (long long)n, ncap, nullptr, 0, g, 0, g.ne, 1, 0, run);
+    if (r == SDR_OK)
+        r = launch_front_and_back(h, x, (long long)stride, (long long)n, ncap, nullptr, 0, g, 0, g.ne, 1, 0, run);
     h->out_count = saved;
     if (r) return r;
     h->last_ncap = ncap;
@@ -774,8 +886,20 @@ extern "C" int sdr_process_iq(sdr_handle* h, const void* iq, size_t n, int is_de
     CallGeom g;
     const long long nout = (long long)(m_end - h->out_count);
     const long long in0 = (long long)(h->out_count * D) - (long long)A;
-    fill_geom(h, nout, in0, h->keep_ctr - 1, g);
-    int r = stream_decode_step(h, g, x, (long long)n, true, out, n);
+    fill_geom(h, nout, in0, h->keep_ctr - 1, g, h->squelch_on);
+    int r;
+    long long nkept = nout;  // items that reach the slicer
+    if (h->squelch_on) {
+        // the gate makes the item count data dependent: one 4-byte read-back per call
+        r = launch_squelch_stage(h, x, 0, (long long)n, 1, h->d_hist[h->hist_sel], h->hist_len, g, 0);
+        if (r) return r;
+        int32_t cnt = 0;
+        HIPCHK(h, hipMemcpyAsync(&cnt, h->d_sq_cnt, sizeof cnt, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        nkept = cnt;
+        fill_geom_gated(h, nkept, h->keep_ctr - 1, g);
+    }
+    r = stream_decode_step(h, g, x, (long long)n, true, out, n);
     if (r) return r;
     // history for the next call: last hist_len samples of (hist ++ x)
     if (n) {
@@ -794,10 +918,10 @@ extern "C" int sdr_process_iq(sdr_handle* h, const void* iq, size_t n, int is_de
     h->in_count = A + n;
     h->out_count = m_end;
     if (g.ne == 0)
-        h->keep_ctr -= nout;
+        h->keep_ctr -= nkept;
     else {
         long long last = g.keep_c0 + (g.ne - 1) * c.keep_n;
-        h->keep_ctr = c.keep_n - (nout - 1 - last);
+        h->keep_ctr = c.keep_n - (nkept - 1 - last);
     }
     return SDR_OK;
 }
@@ -875,6 +999,18 @@ extern "C" int sdr_fetch_demod(sdr_handle* h, float* outp, size_t cap, size_t* n
     const float* src = (h->cfg.post_ntaps > 0 && h->d_tap2) ? h->d_tap2 : h->d_tap;
     HIPCHK(h, hipMemcpy2D(outp, w * sizeof(float), src, (size_t)h->tap_stride * sizeof(float), w * sizeof(float),
                           (size_t)h->last_ncap, hipMemcpyDeviceToHost));
+    return SDR_OK;
+}
+
+extern "C" int sdr_fetch_squelch_counts(sdr_handle* h, int32_t* outp, size_t cap, size_t* n)
+{
+    if (!h || !n) return fail(h, SDR_E_ARG, "sdr_fetch_squelch_counts: bad argument");
+    if (!h->squelch_on) return fail(h, SDR_E_ARG, "sdr_fetch_squelch_counts: no squelch configured");
+    (void)hipSetDevice(h->device);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    *n = (size_t)h->last_ncap;
+    if (!outp || cap < *n || *n == 0) return SDR_OK;
+    HIPCHK(h, hipMemcpy(outp, h->d_sq_cnt, *n * sizeof(int32_t), hipMemcpyDeviceToHost));
     return SDR_OK;
 }
 
