@@ -245,6 +245,32 @@ SDR_API int sdr_fm_process(sdr_fm* h, const void* iq, size_t n, int is_device_pt
 SDR_API int sdr_fm_fetch(sdr_fm* h, int stage, float* out, size_t cap, size_t* n);
 SDR_API const char* sdr_fm_last_error(sdr_fm* h);
 
+/* ---- somfy wake-up (preamble) finder block ----------------------------------
+ * ref: somfy/epy_block_1.py:14-67 `blk(gr.sync_block)`, in_sig=[np.byte],
+ * out_sig=[np.byte]; embedded in somfy/Telis1RTS.grc:892-945.  One handle = one
+ * block instance (state, preamble, position persist between work() calls).
+ * sdr_preamble_work == blk.work(input_items, output_items): n bytes in, n bytes
+ * out (both host, or both device when is_device_ptr).  `info` returns the block
+ * attributes after the call and which of the reference's print lines the call
+ * produced: events bit0 "position of preamble" (value preamble_pos), bit1 the
+ * state-1 "(len, sum)" line (sum8), bit2 "length of preamble" (value preamble),
+ * bit3 np.gradient on fewer than 2 items (the reference raises ValueError after
+ * updating its state; nothing is written to out). */
+typedef struct sdr_preamble_info {
+    int32_t state;
+    int32_t preamble;
+    int64_t position;
+    int32_t events;
+    int32_t sum8;         /* the chunk sum as the reference computes it (int8 arithmetic) */
+    int64_t preamble_pos;
+} sdr_preamble_info;
+typedef struct sdr_preamble sdr_preamble;
+SDR_API int sdr_preamble_create(sdr_preamble** out);
+SDR_API int sdr_preamble_destroy(sdr_preamble* h);
+SDR_API int sdr_preamble_work(sdr_preamble* h, const int8_t* in, size_t n, int is_device_ptr, int8_t* out,
+                              sdr_preamble_info* info);
+SDR_API const char* sdr_preamble_last_error(sdr_preamble* h);
+
 SDR_API int sdr_version(void);
 
 #ifdef __cplusplus

@@ -372,42 +372,64 @@ class SomfySniffer(object):
             self.state = 0
 
 
+def _wrap8(v):
+    """two's-complement int8 of a Python int"""
+    return ((int(v) + 128) & 0xFF) - 128
+
+
 class SomfyPreambleBlock(object):
-    """somfy/epy_block_1.py:14-67 (work() only; the gr.sync_block plumbing is
-    not part of the arithmetic)."""
+    """somfy/epy_block_1.py:14-67, the arithmetic of work() spelled out.
+
+    The reference adds up the chunk with the builtin sum() over np.int8 items:
+    numpy scalar arithmetic, so the total wraps modulo 256 into int8 (numpy 1.x and
+    2.x alike), and `preamble` (an np.int8 after its first assignment) wraps the
+    same way.  `position - preamble` widens under the value-based casting of the
+    numpy 1.x the reference was written for; that is what is restated (numpy 2
+    would raise OverflowError for positions beyond 127).  np.gradient(x, 0.5) of a
+    byte chunk is, cast back to bytes: 2*(x[1]-x[0]), x[i+1]-x[i-1], 2*(x[-1]-x[-2]),
+    and raises ValueError for chunks shorter than 2."""
 
     def __init__(self, bit_length=1e-6):
         self.bit_length = bit_length
         self.state = 0
         self.preamble = 0
         self.position = 0
-        self.prints = []
+        self.prints = [("length of one sample", bit_length)]
 
     def work(self, input_items, output_items):
-        self.position = self.position + len(input_items[0])
+        x = np.asarray(input_items[0]).astype(np.int64)
+        out = output_items[0]
+        n = x.size
+        s8 = _wrap8(x.sum())
+        self.position += n
         if self.state == 0:
-            if sum(input_items[0]) > 0:
-                self.preamble = sum(input_items[0])
+            if s8 > 0:
+                self.preamble = s8
                 self.prints.append(("position of preamble", self.position - self.preamble))
                 self.state = 1
-                zeros = np.zeros(len(input_items[0]))
-                zeros[np.nonzero(input_items[0])[0][0]] = 1.
-                output_items[0][:] = zeros
+                out[:] = 0
+                out[int(np.flatnonzero(x)[0])] = 1
             else:
-                output_items[0][:] = [0]
+                out[:] = 0
         elif self.state == 1:
-            self.prints.append((len(input_items[0]), sum(input_items[0])))
-            if sum(input_items[0]) < len(input_items[0]):
-                self.preamble = self.preamble + sum(input_items[0])
+            self.prints.append((n, s8))
+            self.preamble = _wrap8(self.preamble + s8)
+            if s8 < n:
                 self.state = 2
                 self.prints.append(("length of preamble", self.preamble))
-                output_items[0][:] = np.gradient(input_items[0], 0.5)
+                if n < 2:
+                    raise ValueError("Shape of array too small to calculate a numerical gradient, "
+                                     "at least (edge_order + 1) elements are required.")
+                g = np.empty(n, np.int64)
+                g[1:-1] = x[2:] - x[:-2]
+                g[0] = 2 * (x[1] - x[0])
+                g[-1] = 2 * (x[-1] - x[-2])
+                out[:] = g.astype(np.int8)
             else:
-                self.preamble = self.preamble + sum(input_items[0])
-                output_items[0][:] = [1]
+                out[:] = 1
         else:
-            output_items[0][:] = [1]
-        return len(output_items[0])
+            out[:] = 1
+        return len(out)
 
 
 # -------------------------------------------------------------------- berner

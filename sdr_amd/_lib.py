@@ -114,6 +114,17 @@ class FmCfg(C.Structure):
     ]
 
 
+class PreambleInfo(C.Structure):
+    _fields_ = [
+        ("state", C.c_int32),
+        ("preamble", C.c_int32),
+        ("position", C.c_int64),
+        ("events", C.c_int32),
+        ("sum8", C.c_int32),
+        ("preamble_pos", C.c_int64),
+    ]
+
+
 #: every symbol include/sdrhip.h declares (checked by tests/test_abi.py)
 EXPORTS = [
     "sdr_firdes_low_pass", "sdr_resampler_taps", "sdr_create", "sdr_destroy", "sdr_set_taps",
@@ -121,7 +132,8 @@ EXPORTS = [
     "sdr_process_bits", "sdr_batch_process", "sdr_fetch_frames", "sdr_fetch_bits", "sdr_fetch_demod",
     "sdr_decoder_state", "sdr_timer_start", "sdr_timer_stop", "sdr_timer_elapsed_ms", "sdr_version",
     "sdr_profile_enable", "sdr_profile_read", "sdr_export_frames", "sdr_set_squelch",
-    "sdr_fetch_squelch_counts",
+    "sdr_fetch_squelch_counts", "sdr_preamble_create", "sdr_preamble_destroy", "sdr_preamble_work",
+    "sdr_preamble_last_error",
     "sdr_fm_create", "sdr_fm_destroy", "sdr_fm_set_stream", "sdr_fm_process", "sdr_fm_fetch",
     "sdr_fm_last_error",
 ]
@@ -200,6 +212,14 @@ def load():
     L.sdr_fm_fetch.argtypes = [H, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.sdr_fm_last_error.restype = C.c_char_p
     L.sdr_fm_last_error.argtypes = [H]
+    L.sdr_preamble_create.restype = C.c_int
+    L.sdr_preamble_create.argtypes = [C.POINTER(H)]
+    L.sdr_preamble_destroy.restype = C.c_int
+    L.sdr_preamble_destroy.argtypes = [H]
+    L.sdr_preamble_work.restype = C.c_int
+    L.sdr_preamble_work.argtypes = [H, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.POINTER(PreambleInfo)]
+    L.sdr_preamble_last_error.restype = C.c_char_p
+    L.sdr_preamble_last_error.argtypes = [H]
     # host-compiled test hooks (csrc/selftest.h); not used by the product path
     L.sdr_selftest_hist_mid_edge.restype = C.c_int
     L.sdr_selftest_hist_mid_edge.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double)]

@@ -1095,4 +1095,5 @@ extern "C" int sdr_export_frames(sdr_handle* h, void* frames_dev, size_t frames_
 }
 
 #include "fm_host.h"
+#include "preamble_host.h"
 #include "selftest.h"

@@ -27,7 +27,18 @@ def test_struct_mirrors_match_header_sizes():
     assert C.sizeof(_lib.Frame) == 96
     assert C.sizeof(_lib.ChainCfg) == 80
     assert C.sizeof(_lib.Out) == 32
+    assert C.sizeof(_lib.PreambleInfo) == 32
     assert _lib.load().sdr_version() >= 100
+
+
+def test_no_gpu_blocks_fail_loudly():
+    import torch
+    if torch.cuda.is_available():
+        return
+    import pytest
+    from sdr_amd import somfy
+    with pytest.raises(_lib.SdrError):
+        somfy.blk()
 
 
 def test_firdes_is_host_only_and_matches_oracle():

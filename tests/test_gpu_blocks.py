@@ -109,3 +109,56 @@ def test_somfy_decode_kat(kat):
     assert r == want
     assert r["payload"].hex() == k["payload_hex"] and r["frame"].hex() == k["frame_hex"] and r["checksum_ok"]
     assert (r["control"], r["rolling_code"], r["address"]) == (1, 5, 0x365240)
+
+
+def _preamble_lines(prints):
+    """oracle print records -> the text print() would have produced"""
+    return [" ".join(str(v) for v in p) for p in prints]
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_somfy_preamble_blk_vs_oracle(seed, capsys):
+    """somfy/epy_block_1.py blk: same outputs, attributes and printed lines for a
+    wake-up pulse cut into ragged work() chunks (incl. chunks > 127 items, where
+    the reference's int8 sum wraps)."""
+    from sdr_amd import somfy
+    rng = np.random.default_rng(seed)
+    lead, pulse = int(rng.integers(10, 400)), int(rng.integers(50, 900))
+    stream = np.r_[np.zeros(lead), np.ones(pulse), (rng.random(600) < 0.5)].astype(np.int8)
+    cuts = np.unique(np.r_[0, rng.integers(0, stream.size, 9), stream.size])
+    want = odec.SomfyPreambleBlock(bit_length=2e-6)
+    got = somfy.blk(bit_length=2e-6)
+    assert got.in_sig == [np.byte] and got.out_sig == [np.byte] and got.bit_length == 2e-6
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        c = stream[a:b]
+        if c.size < 2:
+            continue
+        ow, og = np.full(c.size, 7, np.int8), np.full(c.size, 9, np.int8)
+        assert want.work([c], [ow]) == got.work([c], [og]) == c.size
+        np.testing.assert_array_equal(og, ow)
+        assert (got.state, got.preamble, got.position) == (want.state, want.preamble, want.position)
+    assert capsys.readouterr().out.splitlines() == _preamble_lines(want.prints)
+    got.close()
+
+
+def test_somfy_preamble_blk_gradient_error_and_large_chunk(capsys):
+    from sdr_amd import somfy
+    b, o = somfy.blk(), odec.SomfyPreambleBlock()
+    for blkobj in (b, o):
+        blkobj.work([np.array([1], np.int8)], [np.zeros(1, np.int8)])
+        with pytest.raises(ValueError):
+            blkobj.work([np.array([0], np.int8)], [np.zeros(1, np.int8)])
+    assert (b.state, b.preamble, b.position) == (o.state, o.preamble, o.position) == (2, 1, 2)
+    b.close()
+    # one large chunk, float32 output array as a caller might hand over
+    rng = np.random.default_rng(5)
+    x = np.r_[np.zeros(100000), np.ones(30), rng.random(200000) < 0.3].astype(np.int8)
+    b, o = somfy.blk(), odec.SomfyPreambleBlock()
+    for _ in range(3):
+        og, ow = np.zeros(x.size, np.int8), np.zeros(x.size, np.int8)
+        b.work([x], [og])
+        o.work([x], [ow])
+        np.testing.assert_array_equal(og, ow)
+        assert (b.state, b.preamble, b.position) == (o.state, o.preamble, o.position)
+    capsys.readouterr()
+    b.close()

@@ -171,3 +171,50 @@ def test_berner_sniffer(kat):
         s.cbf(lvl, tick)
     # every other frame: the next preamble pulse is consumed as the end marker
     assert s.frames == [bytes.fromhex(kat["berner_example"]["code_hex"])] * 3
+
+
+# ---- somfy preamble block (a12): the reference holds no vectors for it; the
+# restated arithmetic is checked against numpy evaluating the reference's own
+# expressions (builtin sum over int8 items, np.gradient(x, 0.5) cast to bytes)
+def test_somfy_preamble_block_arithmetic_matches_numpy_expressions():
+    import warnings
+    from oracle.decoders import SomfyPreambleBlock
+    rng = np.random.default_rng(12)
+    blk = SomfyPreambleBlock()
+    chunks = [np.zeros(40, np.int8), np.r_[np.zeros(17), np.ones(23)].astype(np.int8), np.ones(50, np.int8),
+              np.ones(300, np.int8), (rng.random(64) < 0.5).astype(np.int8), np.ones(8, np.int8)]
+    states, outs = [], []
+    for c in chunks:
+        o = np.full(c.size, 99, np.int8)
+        assert blk.work([c], [o]) == c.size
+        states.append((blk.state, blk.preamble, blk.position))
+        outs.append(o)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        s1 = int(sum(chunks[1]))          # 23
+        s2 = int(sum(chunks[2]))          # 50: all ones -> still state 1
+        s3 = int(sum(chunks[3]))          # 300 wraps to 44 in int8 -> 44 < 300 -> state 2
+    assert (s1, s2, s3) == (23, 50, 44)
+    assert states[0] == (0, 0, 40)
+    assert states[1] == (1, 23, 80)
+    assert states[2] == (1, 73, 130)
+    assert states[3] == (2, ((73 + 44 + 128) & 0xff) - 128, 430)
+    assert not outs[0].any()
+    assert outs[1].sum() == 1 and outs[1][17] == 1
+    assert (outs[2] == 1).all()
+    np.testing.assert_array_equal(outs[3], np.gradient(chunks[3], 0.5).astype(np.int8))
+    assert (outs[4] == 1).all() and (outs[5] == 1).all()
+    assert ("position of preamble", 80 - 23) in blk.prints and ("length of preamble", states[3][1]) in blk.prints
+    # gradient branch on a mixed chunk
+    b2 = SomfyPreambleBlock()
+    b2.work([np.array([0, 1], np.int8)], [np.zeros(2, np.int8)])
+    c = np.array([1, 1, 0, 1, 0, 0, 1, 1], np.int8)
+    o = np.zeros(8, np.int8)
+    b2.work([c], [o])
+    np.testing.assert_array_equal(o, np.gradient(c, 0.5).astype(np.int8))
+    # np.gradient refuses a 1-item chunk after the state has already moved on
+    b3 = SomfyPreambleBlock()
+    b3.work([np.array([1], np.int8)], [np.zeros(1, np.int8)])
+    with pytest.raises(ValueError):
+        b3.work([np.array([0], np.int8)], [np.zeros(1, np.int8)])
+    assert b3.state == 2
