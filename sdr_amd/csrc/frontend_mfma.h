@@ -1,0 +1,255 @@
+// Channel filter for SMALL decimations (fp32-FMA bound: 4*ntaps/D flop per input
+// sample, SURVEY.md 8d "fp32 vector FMA for a2 at D=1 (shape R)") on the f32
+// matrix cores.  v_mfma_f32_16x16x4_f32 is bit for bit a k-ordered fmaf chain
+// (one rounding per product, no wider accumulation), so the FIR written as a
+// banded Toeplitz product keeps the oracle's numeric contract exactly:
+//
+//   Y[i][g] = sum_k  A[i][k] * B[k][g]      i = output inside a group of 16
+//   A[i][k] = rtaps[k - i*D]  (0 outside the taps)        g = group of 16 outputs
+//   B[k][g] = x[16*D*g + k]   (re and im as two products sharing A)
+//
+// Row i's non-zero terms appear with ascending tap index = oldest sample first,
+// the zero terms are fma(0, x, acc) = acc.  K = 15*D + ntaps, i.e. a fraction
+// ntaps/(15*D+ntaps) of the MFMA work is useful (89 % for 121 taps, D = 1).
+// Limitation: a non-finite input sample (0*Inf) also spoils the <= 15 outputs of
+// its group whose window does not contain it.
+//
+// One wavefront = 256 outputs (16 groups x 16); a workgroup of nw <= 4 waves
+// stages (256*nw-1)*D + ntaps samples in LDS.  Group g of a wave reads its
+// samples with ds_read_b64 at stride 16*D samples: one 16-B pad after every
+// 16*D samples makes the 32 lanes of a half-wave hit 32 distinct bank pairs
+// ((8D+1) is odd).  The staging DMA (global_load_lds, 16 B per lane) writes the
+// padded image directly: LDS chunk c takes source chunk c - c/(8D+1).
+// After the K loop the tile's outputs go through LDS into output order and the
+// epilogue (NCO, demod, gain, hysteresis scan, slicer, keep_one_in_n) runs with
+// 4 consecutive outputs per thread.
+#pragma once
+#include "frontend_kernels.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Hysteresis + slicer for 4 consecutive outputs per thread (see slice_tile).
+__device__ __forceinline__ void slice_tile_x4(const bool* valid, const float* v, long long o_first, long long o_base,
+                                              float lo, float hi, int keep_n, long long keep_c0,
+                                              int8_t* __restrict__ bits, TileSum* __restrict__ ts_out,
+                                              int* __restrict__ sh /* 12 ints */)
+{
+    int evt[4], has = 0, last = 0, firstk = 0;
+#pragma unroll
+    for (int e = 3; e >= 0; --e) {
+        evt[e] = valid[e] ? (v[e] > hi ? 1 : (v[e] < lo ? 2 : 0)) : 0;
+        if (evt[e]) {
+            if (!has) last = (evt[e] == 1);
+            has = 1;
+            firstk = e;
+        }
+    }
+    const unsigned long long any = __ballot(has);
+    const unsigned long long sset = __ballot(has && last);
+    const int lane = lane_id(), wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    const int fk = __shfl(firstk, any ? __builtin_ctzll(any) : 0);
+    if (lane == 0) {
+        sh[wave] = any != 0;
+        sh[4 + wave] = any ? (int)((sset >> (63 - __builtin_clzll(any))) & 1) : 0;
+        sh[8 + wave] = any ? ((wave * 64 + __builtin_ctzll(any)) * 4 + fk) : -1;
+    }
+    __syncthreads();
+    const unsigned long long below = any & ((1ull << lane) - 1ull);
+    int st = 0;
+    if (below) {
+        st = (int)((sset >> (63 - __builtin_clzll(below))) & 1);
+    } else {
+        for (int w = wave - 1; w >= 0; --w)
+            if (sh[w]) {
+                st = sh[4 + w];
+                break;
+            }
+    }
+    if (threadIdx.x == 0) {
+        int first = -1, lst = 0;
+        for (int w = 0; w < nw; ++w)
+            if (sh[w]) {
+                if (first < 0) first = sh[8 + w];
+                lst = sh[4 + w];
+            }
+        ts_out->first_evt = first < 0 ? -1 : (int32_t)(o_base + first);
+        ts_out->last_state = lst;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if (evt[e] == 1)
+            st = 1;
+        else if (evt[e] == 2)
+            st = 0;
+        const long long o = o_first + e;
+        if (valid[e] && o >= keep_c0) {
+            const long long r = o - keep_c0;
+            if (keep_n == 1)
+                bits[r] = (int8_t)st;
+            else if (r % keep_n == 0)
+                bits[r / keep_n] = (int8_t)st;
+        }
+    }
+}
+
+// blockDim.x = 64*nw, P.tile_out = 256*nw - q.  Dynamic LDS: tap table | padded samples (aliased by the output tile).
+__global__ void __launch_bounds__(256) k_frontend_mfma(FrontParams P)
+{
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    __shared__ int sh[12];
+    float* const ldsf = reinterpret_cast<float*>(smem_raw);
+
+    const int T = blockDim.x, nw = T >> 6, TB = nw * 256;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int tile = blockIdx.x, cap = blockIdx.y;
+    const int D = P.D, ntaps = P.ntaps, BK = 16 * D;
+    const int q = (P.demod == SDR_DEMOD_QUAD) ? 1 : 0;
+    const long long o0 = (long long)tile * P.tile_out;
+    const long long m_t0 = o0 - q;                         // FIR output index of the tile's first output
+    const float2* __restrict__ x = P.x + (long long)cap * P.stride;
+    const long long lo_idx = P.in0 + m_t0 * D - (ntaps - 1);  // first input sample of the tile
+    const int ksteps = (15 * D + ntaps + 3) >> 2;
+    const int ntl = (15 * D + 4 * (ksteps + 1) + 3) & ~3;  // tap table floats (+1 step: operand prefetch), 16-B multiple
+    const int npos = (TB - 1) * D + ntaps + 10;            // staged sample positions (K rounding, alignment, prefetch slack)
+    float* const smp = ldsf + ntl;
+
+    // ---- tap table: tapL[15D + idx] = rtaps[idx], zero outside
+    for (int i = t; i < ntl; i += T) {
+        const int idx = i - 15 * D;
+        ldsf[i] = (idx >= 0 && idx < ntaps) ? P.rtaps[idx] : 0.f;
+    }
+
+    // ---- stage the samples in the padded layout: position p -> float 2p + 4*(p / BK)
+    auto fetch = [&](long long idx) -> float2 {
+        if (idx >= 0) return idx < P.n ? x[idx] : make_float2(0.f, 0.f);
+        if (P.hist && idx >= -(long long)P.hist_len) return P.hist[P.hist_len + idx];
+        return make_float2(0.f, 0.f);
+    };
+    const long long gidx = (long long)cap * P.stride + lo_idx;
+    int odd = (int)(gidx & 1);
+    const long long lo_al = lo_idx - odd;
+    const int nsrc = (npos + odd + 1) >> 1;                // 16-B source chunks
+    const bool interior = P.vec_ok && !P.pre_tab && lo_al >= 0 && (lo_al + 2LL * nsrc) <= P.n;
+    if (interior) {
+        const int per = 8 * D + 1;                         // LDS chunks per pad block (last one is the pad)
+        const int nlds = nsrc + nsrc / (8 * D) + 1;
+        const float2* src = x + lo_al;
+        for (int c0 = (t & ~63); c0 < nlds; c0 += T) {
+            const int c = c0 + lane;
+            const int blk = c / per, r = c - blk * per;
+            const int sc = blk * 8 * D + r;
+            if (c < nlds && r < 8 * D && sc < nsrc)
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void*)(src + 2 * sc),
+                    (__attribute__((address_space(3))) void*)(smp + 4 * c0), 16, 0, 0);
+        }
+    } else {
+        odd = 0;
+        for (int p = t; p < npos; p += T) {
+            const long long idx = lo_idx + p;
+            float2 v = fetch(idx);
+            if (P.pre_tab) {
+                const float2 r = nco_eval(P.pre_tab, (P.pre_idx0 + (unsigned long long)idx) * P.pre_inc);
+                v = make_float2(__builtin_fmaf(v.x, r.x, -(v.y * r.y)), __builtin_fmaf(v.x, r.y, v.y * r.x));
+            }
+            *reinterpret_cast<float2*>(smp + 2 * p + 4 * (p / BK)) = v;
+        }
+    }
+    __syncthreads();
+
+    // ---- banded Toeplitz product on the f32 matrix cores
+    f32x4 accR = {0.f, 0.f, 0.f, 0.f}, accI = {0.f, 0.f, 0.f, 0.f};
+    {
+        const int g = lane & 15, kq = lane >> 4;
+        const int G = wave * 16 + g;                       // group index inside the workgroup tile
+        const float* ta = ldsf + (15 * D + kq - D * g);    // A[i=g][k]: tap index 4kk + kq - g*D
+        int u = odd + kq;                                  // offset inside the pad block (BK >= 16 > u)
+        const float* sb = smp + 2 * (odd + BK * G + kq) + 4 * G;
+        // operands of step kk+1 are fetched while the two MFMAs of step kk run
+        float a = ta[0];
+        float2 b = *reinterpret_cast<const float2*>(sb);
+        for (int kk = 0; kk < ksteps; ++kk) {
+            sb += 8;
+            u += 4;
+            if (u >= BK) {
+                u -= BK;
+                sb += 4;
+            }
+            const float an = ta[4 * kk + 4];
+            const float2 bn = *reinterpret_cast<const float2*>(sb);
+            accR = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b.x, accR, 0, 0, 0);
+            accI = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b.y, accI, 0, 0, 0);
+            a = an;
+            b = bn;
+        }
+    }
+    __syncthreads();  // every wave is done with the samples: the output tile aliases them
+    float2* const ybuf = reinterpret_cast<float2*>(smp);
+    {
+        // D[row = 4*(lane>>4) + r][col = lane&15]: output 16*g + row of this wave's 256
+        const int base = wave * 256 + 16 * (lane & 15) + 4 * (lane >> 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ybuf[base + r] = make_float2(accR[r], accI[r]);
+    }
+    __syncthreads();
+
+    // ---- epilogue: thread t owns outputs 4t .. 4t+3 of the tile
+    float ar[4], ai[4];
+    bool valid[4];
+    const long long m0 = m_t0 + 4LL * t;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const long long m = m0 + e;
+        const bool have_y = (m >= 0 || P.hist != nullptr) && (m < P.nout);
+        float2 y = ybuf[4 * t + e];
+        if (!have_y) y = make_float2(0.f, 0.f);
+        if (have_y && P.nco_tab) {
+            const float2 r = nco_eval(P.nco_tab, (P.nco_m0 + (unsigned long long)m) * P.nco_inc);
+            y = make_float2(__builtin_fmaf(y.x, r.x, -(y.y * r.y)), __builtin_fmaf(y.x, r.y, y.y * r.x));
+        }
+        ar[e] = y.x;
+        ai[e] = y.y;
+        valid[e] = (4 * t + e >= q) && (m < P.nout);
+    }
+    if (P.demod == SDR_DEMOD_NONE) {
+        if (P.tap) {
+            float2* dst = reinterpret_cast<float2*>(P.tap + (long long)cap * P.tap_stride);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (valid[e]) dst[m0 + e] = make_float2(ar[e], ai[e]);
+        }
+        return;
+    }
+    float v[4];
+    if (P.demod == SDR_DEMOD_MAG2) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(ar[e], ar[e], ai[e] * ai[e]);
+    } else {
+        // the previous output of e = 0 belongs to the neighbouring thread: pass the
+        // (rotated, zero-filled) outputs through LDS once more
+        __syncthreads();
+        ybuf[4 * t + 3] = make_float2(ar[3], ai[3]);
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[e] = 0.f;
+            if (valid[e]) {
+                const float2 pv = (e == 0) ? ybuf[4 * t - 1] : make_float2(ar[e - 1], ai[e - 1]);
+                const float tr = __builtin_fmaf(ar[e], pv.x, ai[e] * pv.y);
+                const float ti = __builtin_fmaf(ai[e], pv.x, -(ar[e] * pv.y));
+                v[e] = fast_atan2f_dev(P.atan_tab, ti, tr);
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = P.gain * v[e];
+    if (P.tap) {
+        float* dst = P.tap + (long long)cap * P.tap_stride;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (valid[e]) dst[m0 + e] = v[e];
+    }
+    if (!P.do_slice) return;
+    slice_tile_x4(valid, v, m0, m_t0, P.lo, P.hi, P.keep_n, P.keep_c0, P.bits + (long long)cap * P.bits_stride,
+                  P.tsum + (long long)cap * P.tiles_per_capture + tile, sh);
+}

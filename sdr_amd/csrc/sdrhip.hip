@@ -11,6 +11,7 @@
 
 #include "sdr_common.h"
 #include "frontend_kernels.h"
+#include "frontend_mfma.h"
 #include "backend_kernels.h"
 #include "backend_main.h"
 #include "fm_kernels.h"
@@ -72,6 +73,8 @@ struct sdr_handle {
     long long sq_stride = 0;
     int32_t* d_sq_cnt = nullptr;
     SquelchState* d_sq_st = nullptr;
+
+    int front_mode = 0;  // 0 auto, 1 LDS/VALU kernel only, 2 MFMA kernel whenever it fits (env SDR_FRONTEND=auto|valu|mfma)
 
     // internal modes used by the FM chain (fm_host.h)
     bool prerotate = false;   // center_freq applies to the INPUT samples (xlating taps=[1] then FIR)
@@ -338,6 +341,36 @@ static void pick_tile(const sdr_handle* h, int& T, size_t& lds, bool& use_lds)
     lds = 0;
 }
 
+// k_frontend_mfma (frontend_mfma.h): LDS bytes for nw wavefronts, 0 if it does not fit
+static size_t mfma_lds_bytes(int D, int ntaps, int nw)
+{
+    const long long TB = 256LL * nw, BK = 16LL * D;
+    const long long ksteps = (15LL * D + ntaps + 3) >> 2;
+    const long long ntl = (15LL * D + 4 * (ksteps + 1) + 3) & ~3LL;
+    const long long npos = (TB - 1) * D + ntaps + 10 + 2;
+    const long long smp = 2 * npos + 4 * (npos / BK + 2);
+    const long long bytes = (ntl + smp) * 4;
+    return bytes <= 60 * 1024 ? (size_t)bytes : 0;
+}
+
+// The matrix-core kernel pays when the filter is fp32-FMA bound: real taps and
+// enough flops per input sample that the LDS-walking kernel is not HBM bound.
+static bool pick_mfma(const sdr_handle* h, int& T, size_t& lds)
+{
+    if (h->front_mode == 1 || h->rt_complex) return false;
+    const int D = h->cfg.decim, nt = h->ntaps;
+    if (h->front_mode == 0 && 4.0 * nt / D < 24.0) return false;
+    for (int nw = 4; nw >= 1; nw >>= 1) {
+        size_t b = mfma_lds_bytes(D, nt, nw);
+        if (b) {
+            T = 64 * nw;
+            lds = b;
+            return true;
+        }
+    }
+    return false;
+}
+
 // ------------------------------------------------------------------ create
 extern "C" int sdr_version(void) { return 100; }
 
@@ -379,6 +412,8 @@ extern "C" int sdr_create(const sdr_chain_cfg* cfg, sdr_handle** out)
         delete h;
         return fail(nullptr, SDR_E_HIP, "hipGetDevice failed");
     }
+    if (const char* fm = getenv("SDR_FRONTEND"))
+        h->front_mode = !strcmp(fm, "valu") ? 1 : (!strcmp(fm, "mfma") ? 2 : 0);
     (void)hipDeviceGetAttribute(&h->num_cus, hipDeviceAttributeMultiprocessorCount, h->device);
     if (h->num_cus < 1) h->num_cus = 256;
     int rc = SDR_OK;
@@ -557,6 +592,7 @@ struct CallGeom {
     int T, tile_out, tiles;
     size_t lds;
     bool use_lds;
+    bool mfma;   // k_frontend_mfma: T = 64*nw threads, 256*nw FIR outputs per tile
 };
 
 // channel filter (+ demod + slicer unless the output goes to the squelch stage)
@@ -610,7 +646,9 @@ static int launch_front(sdr_handle* h, const float2* x, long long stride, long l
     } else if (c.demod == SDR_DEMOD_NONE && !h->d_tap)
         return fail(h, SDR_E_ARG, "demod NONE needs cfg.tap_demod (complex output buffer)");
     dim3 grid(g.tiles, ncap), block(g.T);
-    if (g.use_lds)
+    if (g.mfma)
+        hipLaunchKernelGGL(k_frontend_mfma, grid, block, g.lds, h->stream, P);
+    else if (g.use_lds)
         hipLaunchKernelGGL(k_frontend<true>, grid, block, g.lds, h->stream, P);
     else
         hipLaunchKernelGGL(k_frontend<false>, grid, block, 0, h->stream, P);
@@ -761,8 +799,15 @@ static void fill_geom(const sdr_handle* h, long long nout, long long in0, long l
     g.keep_c0 = keep_c0;
     const long long kn = h->cfg.keep_n;
     g.ne = nout > keep_c0 ? (nout - keep_c0 + kn - 1) / kn : 0;
-    pick_tile(h, g.T, g.lds, g.use_lds);
-    g.tile_out = g.T - ((h->cfg.demod == SDR_DEMOD_QUAD && !to_squelch) ? 1 : 0);
+    const int q = (h->cfg.demod == SDR_DEMOD_QUAD && !to_squelch) ? 1 : 0;
+    g.mfma = pick_mfma(h, g.T, g.lds);
+    if (g.mfma) {
+        g.use_lds = true;
+        g.tile_out = 4 * g.T - q;
+    } else {
+        pick_tile(h, g.T, g.lds, g.use_lds);
+        g.tile_out = g.T - q;
+    }
     g.tiles = (int)((nout + g.tile_out - 1) / g.tile_out);
 }
 
