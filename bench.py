@@ -35,7 +35,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 BYTES_PER_SAMPLE = 8.0 + 1.0 / DECIM  # complex64 in + sliced byte out
 
 
-def make_batch(torch, dev, ncap, seed):
+def make_batch(torch, dev, ncap, seed, FS=FS, N_PER_CAPTURE=N_PER_CAPTURE, F_OFF=F_OFF):
     """Synthetic captures built on the GPU: host makes the 0/1 envelopes of two
     TS33C frames per capture (random payloads), the GPU applies carrier + AWGN."""
     from sdr_amd import synth
@@ -127,6 +127,68 @@ def fm_workload(torch, dev, skip_cpu, n=1 << 24, fs=2.4e6, steps=20):
             raise SystemExit("FM audio differs from the oracle: rel err %g" % err)
         out["verified"] = "audio of the first 2^22 samples within 1e-5 of the oracle (rel err %.1e)" % err
     r.close()
+    return out
+
+
+FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32 vector peak = f32-input MFMA peak
+
+
+def r_shape_workload(torch, dev, skip_cpu, ncap=64, n=1 << 19, fs=2e6, steps=20):
+    """Secondary line: the reference-faithful "R" shape of SURVEY 8d-1 = TS33C/live_decoder.grc
+    as wired (samp_rate 2e6, low_pass_filter 20k/40k Hamming = 121 taps at decimation 1,
+    mag^2, threshold .05/.15, keep_one_in_n(100), decoder at 20 kHz).  484 flop per input
+    sample: fp32-FMA bound, runs on the f32 matrix cores (k_frontend_mfma)."""
+    from sdr_amd import chain, _lib
+    iq, pkts = make_batch(torch, dev, ncap, seed=33, FS=fs, N_PER_CAPTURE=n, F_OFF=0.0)
+    taps = chain.low_pass(1.0, fs, 20e3, 40e3)
+    c = chain.Chain(fs, decim=1, taps=taps, keep_n=100, decoder=chain.DEC_TS33C, max_batch=ncap, max_frames=4,
+                    max_samples=n)
+    c.set_stream(torch.cuda.current_stream().cuda_stream)
+    for _ in range(3):
+        c.batch_process(iq)
+    torch.cuda.synchronize()
+    c.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        c.batch_process(iq)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    front_ms, back_ms = c.profile_read()
+    got = {}
+    for f in c.fetch_frames():
+        if f.status == _lib.FRAME_OK:
+            got.setdefault(f.capture, []).append(f.packet())
+    n_ok = sum(1 for i in range(ncap) if got.get(i) == [pkts[i], pkts[i]])
+    if n_ok != ncap:
+        raise SystemExit("R shape: only %d of %d captures decoded to the transmitted packets" % (n_ok, ncap))
+    fk = float(np.mean(front_ms))
+    flops = 4.0 * taps.size * ncap * n
+    out = {"value": round(ncap * n / dt / 1e6, 1), "unit": "Msps", "ms_per_step": round(dt * 1e3, 4),
+           "captures": ncap, "samples_per_capture": n, "sample_rate": fs, "ntaps": int(taps.size), "decim": 1,
+           "keep_n": 100, "chain": "fir_filter_ccf->mag2->threshold->slicer->keep_one_in_n->ts33c_decoder",
+           "roofline": {"bound": "mfma", "kernel": "k_frontend_mfma", "achieved": round(flops / (fk * 1e-3) / 1e12, 1),
+                        "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(flops / (fk * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4), "traffic": None,
+                        "kernel_ms": round(fk, 4), "backend_kernel_ms": round(float(np.mean(back_ms)), 4),
+                        "flops_per_launch": flops, "note": "algorithmic flops = 4*ntaps per input sample (real taps); "
+                        "the banded-Toeplitz MFMA form issues (15+ntaps)/ntaps times that"},
+           "verified": "all captures decode to the transmitted packets"}
+    if not skip_cpu:
+        from oracle import decoders as odec
+        from oracle import dsp as odsp
+        bits = c.fetch_bits().reshape(ncap, -1)
+        x = iq[0].cpu().numpy().view(np.complex64).reshape(-1)
+        t0 = time.perf_counter()
+        want = odsp.ook_chain(x, taps, 1, 1.0, 0.05, 0.15, 100)
+        d = odec.TS33CStreamDecoder(sample_rate=20000)
+        d.work([want])
+        tc = time.perf_counter() - t0
+        if not np.array_equal(bits[0], want) or [f["packet"] for f in d.frames] != got.get(0):
+            raise SystemExit("R shape: capture 0 differs from the oracle")
+        out["cpu_baseline"] = {"value": round(n / tc / 1e6, 2), "unit": "Msps", "cores": 1, "kind": "port",
+                               "sample": "capture 0 (2^19 samples), oracle C chain + numpy TS33C decoder, %.2f s" % tc}
+        out["verified"] += "; capture 0 bit-exact vs oracle"
+    c.close()
     return out
 
 
@@ -263,7 +325,8 @@ def main():
         if world == 1:
             del iq
             torch.cuda.empty_cache()
-            line["other_workloads"] = {"fm_radio_wbfm": fm_workload(torch, dev, args.no_cpu_baseline)}
+            line["other_workloads"] = {"fm_radio_wbfm": fm_workload(torch, dev, args.no_cpu_baseline),
+                                       "ook_r_shape_ts33c": r_shape_workload(torch, dev, args.no_cpu_baseline)}
         print(json.dumps(line))
     c.close()
     if world > 1:

@@ -118,7 +118,10 @@ __device__ __forceinline__ void slice_tile(bool valid, float v, long long o, lon
         long long r = o - keep_c0;
         if (keep_n == 1)
             bits[r] = (int8_t)st;
-        else if (r % keep_n == 0)
+        else if (r < 0x7fffffffLL) {  // 32-bit division: the 64-bit one costs ~10x
+            const unsigned qq = (unsigned)r / (unsigned)keep_n;
+            if ((unsigned)r == qq * (unsigned)keep_n) bits[qq] = (int8_t)st;
+        } else if (r % keep_n == 0)
             bits[r / keep_n] = (int8_t)st;
     }
 }

@@ -75,19 +75,37 @@ __device__ __forceinline__ void slice_tile_x4(const bool* valid, const float* v,
         ts_out->first_evt = first < 0 ? -1 : (int32_t)(o_base + first);
         ts_out->last_state = lst;
     }
+    // keep_one_in_n: one division per thread (32-bit when the index allows), then
+    // the remainder is stepped along the thread's 4 outputs
+    const long long r0 = o_first - keep_c0;
+    long long quo = 0;
+    int rem = 0;
+    if (keep_n > 1 && r0 + 3 >= 0) {
+        const long long rb = r0 < 0 ? 0 : r0;  // first non-negative index of this thread
+        if (rb < 0x7fffffffLL) {
+            quo = (unsigned)rb / (unsigned)keep_n;
+            rem = (int)((unsigned)rb - (unsigned)quo * (unsigned)keep_n);
+        } else {
+            quo = rb / keep_n;
+            rem = (int)(rb - quo * keep_n);
+        }
+    }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         if (evt[e] == 1)
             st = 1;
         else if (evt[e] == 2)
             st = 0;
-        const long long o = o_first + e;
-        if (valid[e] && o >= keep_c0) {
-            const long long r = o - keep_c0;
-            if (keep_n == 1)
-                bits[r] = (int8_t)st;
-            else if (r % keep_n == 0)
-                bits[r / keep_n] = (int8_t)st;
+        const long long r = r0 + e;
+        if (r < 0) continue;
+        if (keep_n == 1) {
+            if (valid[e]) bits[r] = (int8_t)st;
+        } else {
+            if (valid[e] && rem == 0) bits[quo] = (int8_t)st;
+            if (++rem == keep_n) {
+                rem = 0;
+                ++quo;
+            }
         }
     }
 }
@@ -109,8 +127,8 @@ __global__ void __launch_bounds__(256) k_frontend_mfma(FrontParams P)
     const float2* __restrict__ x = P.x + (long long)cap * P.stride;
     const long long lo_idx = P.in0 + m_t0 * D - (ntaps - 1);  // first input sample of the tile
     const int ksteps = (15 * D + ntaps + 3) >> 2;
-    const int ntl = (15 * D + 4 * (ksteps + 1) + 3) & ~3;  // tap table floats (+1 step: operand prefetch), 16-B multiple
-    const int npos = (TB - 1) * D + ntaps + 10;            // staged sample positions (K rounding, alignment, prefetch slack)
+    const int ntl = (15 * D + 4 * (ksteps + 8) + 3) & ~3;  // tap table floats (+2 groups: operand prefetch), 16-B multiple
+    const int npos = (TB - 1) * D + ntaps + 40;            // staged sample positions (K rounding, alignment, prefetch slack)
     float* const smp = ldsf + ntl;
 
     // ---- tap table: tapL[15D + idx] = rtaps[idx], zero outside
@@ -163,25 +181,49 @@ __global__ void __launch_bounds__(256) k_frontend_mfma(FrontParams P)
         const int g = lane & 15, kq = lane >> 4;
         const int G = wave * 16 + g;                       // group index inside the workgroup tile
         const float* ta = ldsf + (15 * D + kq - D * g);    // A[i=g][k]: tap index 4kk + kq - g*D
-        int u = odd + kq;                                  // offset inside the pad block (BK >= 16 > u)
         const float* sb = smp + 2 * (odd + BK * G + kq) + 4 * G;
-        // operands of step kk+1 are fetched while the two MFMAs of step kk run
-        float a = ta[0];
-        float2 b = *reinterpret_cast<const float2*>(sb);
-        for (int kk = 0; kk < ksteps; ++kk) {
-            sb += 8;
-            u += 4;
-            if (u >= BK) {
-                u -= BK;
+        // K steps in groups of 4 (= 16 samples; a pad block is D groups): constant
+        // offsets inside a group, one pointer bump per group, the pad added per
+        // block.  A lane that starts at offset 4 (odd tile start, kq = 3) crosses
+        // into the next block one step early: `late` on the block's last step.
+        const int late = (odd + kq >= 4) ? 4 : 0;
+        const int ngrp = ksteps >> 2, tail = ksteps & 3;
+        int gi = 0;
+        float a[4], an[4];
+        float2 b[4], bn[4];
+        auto load = [&](float* av, float2* bv) {
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) av[s4] = ta[4 * s4];
+#pragma unroll
+            for (int s4 = 0; s4 < 3; ++s4) bv[s4] = *reinterpret_cast<const float2*>(sb + 8 * s4);
+            bv[3] = *reinterpret_cast<const float2*>(sb + 24 + ((gi == D - 1) ? late : 0));
+            ta += 16;
+            sb += 32;
+            if (++gi == D) {
+                gi = 0;
                 sb += 4;
             }
-            const float an = ta[4 * kk + 4];
-            const float2 bn = *reinterpret_cast<const float2*>(sb);
-            accR = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b.x, accR, 0, 0, 0);
-            accI = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b.y, accI, 0, 0, 0);
-            a = an;
-            b = bn;
+        };
+        load(a, b);
+        for (int grp = 0; grp < ngrp; ++grp) {
+            load(an, bn);  // operands of the next group are fetched while this group's 8 MFMAs run
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                accR = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s4], b[s4].x, accR, 0, 0, 0);
+                accI = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s4], b[s4].y, accI, 0, 0, 0);
+            }
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                a[s4] = an[s4];
+                b[s4] = bn[s4];
+            }
         }
+#pragma unroll
+        for (int s4 = 0; s4 < 3; ++s4)
+            if (s4 < tail) {
+                accR = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s4], b[s4].x, accR, 0, 0, 0);
+                accI = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s4], b[s4].y, accI, 0, 0, 0);
+            }
     }
     __syncthreads();  // every wave is done with the samples: the output tile aliases them
     float2* const ybuf = reinterpret_cast<float2*>(smp);

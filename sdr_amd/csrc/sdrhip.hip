@@ -346,8 +346,8 @@ static size_t mfma_lds_bytes(int D, int ntaps, int nw)
 {
     const long long TB = 256LL * nw, BK = 16LL * D;
     const long long ksteps = (15LL * D + ntaps + 3) >> 2;
-    const long long ntl = (15LL * D + 4 * (ksteps + 1) + 3) & ~3LL;
-    const long long npos = (TB - 1) * D + ntaps + 10 + 2;
+    const long long ntl = (15LL * D + 4 * (ksteps + 8) + 3) & ~3LL;
+    const long long npos = (TB - 1) * D + ntaps + 40 + 2;
     const long long smp = 2 * npos + 4 * (npos / BK + 2);
     const long long bytes = (ntl + smp) * 4;
     return bytes <= 60 * 1024 ? (size_t)bytes : 0;

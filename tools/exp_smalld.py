@@ -40,6 +40,8 @@ t329 = chain.resampler_taps(1, 10)
 which = sys.argv[1:] or ["all"]
 if "all" in which or "r" in which:
     run("R-shape ts33c (ccf)", 64, 1 << 18, 1, t121, keep_n=100)
+    run("R-shape 256 captures", 256, 1 << 18, 1, t121, keep_n=100)
+    run("R-shape 64 none", 64, 1 << 18, 1, t121, demod=chain.DEMOD_NONE)
     run("R-shape one stream 2^24", 1, 1 << 24, 1, t121, keep_n=100)
     run("tfa lpf 27 quad", 64, 1 << 18, 1, t27, demod=chain.DEMOD_QUAD)
     run("mumbi stage1 97 none", 64, 1 << 18, 1, t97, demod=chain.DEMOD_NONE)
