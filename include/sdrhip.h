@@ -140,6 +140,14 @@ SDR_API int sdr_destroy(sdr_handle* h);
  * translated as freq_xlating_fir_filter_ccc does. */
 SDR_API int sdr_set_taps(sdr_handle* h, const float* taps, int n, int is_complex);
 SDR_API int sdr_set_post_taps(sdr_handle* h, const float* taps, int n);
+/* An upstream channel-filter stage (fir_filter_ccf, real taps, decimation `decim`)
+ * in front of this chain's own filter, for flowgraphs that cascade two:
+ * ref: mumbi/FS300.grc:731-802 low_pass_filter (97 taps) -> :1691-1746
+ * rational_resampler_ccc 1/10 (its polyphase filter with interpolation 1 IS a
+ * decimating FIR: pass sdr_resampler_taps(1, 10) as this chain's taps, decim 10).
+ * cfg.sample_rate / cfg.max_samples of the chain then refer to the stream BETWEEN
+ * the two stages; sdr_process_iq / sdr_batch_process take the upstream input. */
+SDR_API int sdr_set_prefilter(sdr_handle* h, const float* taps, int n, int decim);
 /* analog_pwr_squelch_cc (ramp 0) between the channel filter and the demodulator:
  * p = alpha*|y|^2 + (1-alpha)*p (double), an item passes iff !(p < 10^(db/10));
  * gate != 0 drops muted items (the stream gets shorter), gate == 0 zeroes them.

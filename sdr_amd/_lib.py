@@ -133,7 +133,7 @@ EXPORTS = [
     "sdr_decoder_state", "sdr_timer_start", "sdr_timer_stop", "sdr_timer_elapsed_ms", "sdr_version",
     "sdr_profile_enable", "sdr_profile_read", "sdr_export_frames", "sdr_set_squelch",
     "sdr_fetch_squelch_counts", "sdr_preamble_create", "sdr_preamble_destroy", "sdr_preamble_work",
-    "sdr_preamble_last_error",
+    "sdr_preamble_last_error", "sdr_set_prefilter",
     "sdr_fm_create", "sdr_fm_destroy", "sdr_fm_set_stream", "sdr_fm_process", "sdr_fm_fetch",
     "sdr_fm_last_error",
 ]
@@ -164,6 +164,8 @@ def load():
     L.sdr_set_taps.argtypes = [H, fp, C.c_int, C.c_int]
     L.sdr_set_post_taps.restype = C.c_int
     L.sdr_set_post_taps.argtypes = [H, fp, C.c_int]
+    L.sdr_set_prefilter.restype = C.c_int
+    L.sdr_set_prefilter.argtypes = [H, fp, C.c_int, C.c_int]
     L.sdr_set_squelch.restype = C.c_int
     L.sdr_set_squelch.argtypes = [H, C.c_double, C.c_double, C.c_int]
     L.sdr_fetch_squelch_counts.restype = C.c_int

@@ -43,13 +43,19 @@ def _is_torch(x):
 class Chain(object):
     def __init__(self, sample_rate, decim=1, center_freq=0.0, taps=None, demod=DEMOD_MAG2, demod_gain=1.0,
                  thr=(0.05, 0.15), thr_init=0, keep_n=1, decoder=DEC_NONE, decoder_rate=0.0, post_taps=None,
-                 tap_demod=False, max_batch=1, max_frames=16, max_samples=1 << 20, squelch=None):
+                 tap_demod=False, max_batch=1, max_frames=16, max_samples=1 << 20, squelch=None,
+                 pre_taps=None, pre_decim=1):
         """squelch=(threshold_db, alpha[, gate=True]): analog_pwr_squelch_cc between the channel
-        filter and the demodulator (TFA/decoder.grc:391-446)."""
+        filter and the demodulator (TFA/decoder.grc:391-446).
+        pre_taps/pre_decim: an upstream fir_filter_ccf in front of this chain's own filter
+        (mumbi/FS300.grc: low_pass_filter -> rational_resampler 1/10); sample_rate and
+        max_samples are then those of the upstream input."""
         self._L = _lib.load()
         self._h = C.c_void_p()
         cfg = _lib.ChainCfg()
-        cfg.sample_rate = float(sample_rate)
+        pre_decim = int(pre_decim) if pre_taps is not None else 1
+        cfg.sample_rate = float(sample_rate) / pre_decim
+        max_samples = -(-int(max_samples) // pre_decim)
         cfg.center_freq = float(center_freq)
         cfg.decim = int(decim)
         cfg.demod = int(demod)
@@ -75,6 +81,10 @@ class Chain(object):
             pt = np.ascontiguousarray(post_taps, np.float32)
             _lib.check(self._h, self._L.sdr_set_post_taps(self._h, pt.ctypes.data_as(C.POINTER(C.c_float)), pt.size))
         self.out = _lib.Out()
+        if pre_taps is not None:
+            pt = np.ascontiguousarray(pre_taps, np.float32)
+            _lib.check(self._h, self._L.sdr_set_prefilter(self._h, pt.ctypes.data_as(C.POINTER(C.c_float)), pt.size,
+                                                          pre_decim))
         if squelch is not None:
             self.set_squelch(*squelch)
 

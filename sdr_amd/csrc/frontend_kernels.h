@@ -351,7 +351,12 @@ __global__ void __launch_bounds__(256) k_post_fir_slice(PostParams P)
     const int count = T + H;
     for (int i = threadIdx.x; i < count; i += T) {
         long long idx = o0 - H + i;
-        lds[i] = (idx >= 0 && idx < P.nout) ? v[idx] : 0.f;
+        float s = 0.f;
+        if (idx >= 0) {
+            if (idx < P.nout) s = v[idx];
+        } else if (P.hist)
+            s = P.hist[H + idx];
+        lds[i] = s;
     }
     __syncthreads();
     const int t = threadIdx.x;

@@ -64,7 +64,8 @@ struct FrontParams {
 };
 
 struct PostParams {         // real FIR on demodulated floats + slicer (TFA/analyzer2.grc chain)
-    const float* v;         // nin floats per capture (zero history)
+    const float* v;         // nout floats per capture
+    const float* hist;      // streaming: the ntaps-1 floats that precede v[0]; nullptr = zeros
     long long v_stride;
     long long nout;
     int ntaps;

@@ -49,6 +49,8 @@ struct sdr_handle {
     long long bits_stride = 0;
     float* d_tap = nullptr;       // demod floats (or complex pairs)
     float* d_tap2 = nullptr;      // post-filter output
+    float* d_post_hist[2] = {nullptr, nullptr};  // streaming history of the post-demod filter
+    int post_hist_sel = 0;
     long long tap_stride = 0;
     TileSum* d_tsum = nullptr;
     int tsum_stride = 0;
@@ -74,6 +76,7 @@ struct sdr_handle {
     int32_t* d_sq_cnt = nullptr;
     SquelchState* d_sq_st = nullptr;
 
+    sdr_handle* pre = nullptr;  // upstream channel-filter stage (sdr_set_prefilter)
     int front_mode = 0;  // 0 auto, 1 LDS/VALU kernel only, 2 MFMA kernel whenever it fits (env SDR_FRONTEND=auto|valu|mfma)
 
     // internal modes used by the FM chain (fm_host.h)
@@ -380,10 +383,16 @@ extern "C" int sdr_destroy(sdr_handle* h)
 {
     if (!h) return SDR_OK;
     (void)hipSetDevice(h->device);
+    if (h->pre) {
+        (void)hipStreamSynchronize(h->stream);
+        sdr_destroy(h->pre);
+        h->pre = nullptr;
+    }
     if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
     void* ptrs[] = {h->d_rtaps, h->d_post_rtaps, h->d_nco_tab, h->d_atan_tab, h->d_pow, h->d_log2, h->d_iq,
                     h->d_hist[0], h->d_hist[1], h->d_bits, h->d_tap, h->d_tap2, h->d_tsum, h->d_runs,
-                    h->d_cur, h->d_st, h->d_frames, h->d_sq_y, h->d_sq_z, h->d_sq_cnt, h->d_sq_st};
+                    h->d_cur, h->d_st, h->d_frames, h->d_sq_y, h->d_sq_z, h->d_sq_cnt, h->d_sq_st,
+                    h->d_post_hist[0], h->d_post_hist[1]};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (hipEvent_t e : h->pev) (void)hipEventDestroy(e);
@@ -445,7 +454,7 @@ extern "C" int sdr_create(const sdr_chain_cfg* cfg, sdr_handle** out)
         if (r) return r;
         // buffers
         const long long B = h->cfg.max_batch;
-        const long long nout_max = (long long)(h->cfg.max_samples / h->cfg.decim) + 2;
+        const long long nout_max = ((long long)(h->cfg.max_samples / h->cfg.decim) + 3) & ~1LL;  // even: rows stay 16-B aligned
         const long long nb_max = nout_max / h->cfg.keep_n + 2;
         h->dec_rate = h->cfg.decoder_rate > 0 ? h->cfg.decoder_rate
                                               : h->cfg.sample_rate / h->cfg.decim / h->cfg.keep_n;
@@ -509,8 +518,47 @@ extern "C" int sdr_set_post_taps(sdr_handle* h, const float* taps, int n)
     std::vector<float> rt(n);
     for (int k = 0; k < n; ++k) rt[n - 1 - k] = taps[k];
     if (!h->d_post_rtaps) HIPCHK(h, dev_alloc((void**)&h->d_post_rtaps, n * sizeof(float)));
+    for (int i = 0; i < 2; ++i) {
+        if (!h->d_post_hist[i]) HIPCHK(h, dev_alloc((void**)&h->d_post_hist[i], (size_t)(n + 1) * sizeof(float)));
+        HIPCHK(h, hipMemset(h->d_post_hist[i], 0, (size_t)(n + 1) * sizeof(float)));
+    }
     HIPCHK(h, hipMemcpy(h->d_post_rtaps, rt.data(), n * sizeof(float), hipMemcpyHostToDevice));
     h->post_taps.assign(taps, taps + n);
+    return SDR_OK;
+}
+
+extern "C" int sdr_set_prefilter(sdr_handle* h, const float* taps, int n, int decim)
+{
+    if (!h || !taps || n < 1 || n > 65536 || decim < 1) return fail(h, SDR_E_ARG, "sdr_set_prefilter: bad argument");
+    (void)hipSetDevice(h->device);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->pre) {
+        sdr_destroy(h->pre);
+        h->pre = nullptr;
+    }
+    sdr_chain_cfg pc;
+    memset(&pc, 0, sizeof pc);
+    pc.sample_rate = h->cfg.sample_rate * decim;
+    pc.decim = decim;
+    pc.demod = SDR_DEMOD_NONE;
+    pc.demod_gain = 1.0f;
+    pc.keep_n = 1;
+    pc.decoder = SDR_DEC_NONE;
+    pc.tap_demod = 1;
+    pc.max_batch = h->cfg.max_batch;
+    pc.max_frames = 1;
+    pc.max_samples = h->cfg.max_samples * (uint64_t)decim;
+    sdr_handle* p = nullptr;
+    int r = sdr_create(&pc, &p);
+    if (r) return fail(h, r, "sdr_set_prefilter: " + g_err);
+    r = sdr_set_taps(p, taps, n, 0);
+    if (r) {
+        std::string e = p->err;
+        sdr_destroy(p);
+        return fail(h, r, "sdr_set_prefilter: " + e);
+    }
+    p->stream = h->stream;
+    h->pre = p;
     return SDR_OK;
 }
 
@@ -542,6 +590,7 @@ extern "C" int sdr_set_stream(sdr_handle* h, void* s)
 {
     if (!h) return SDR_E_ARG;
     h->stream = s ? (hipStream_t)s : h->own_stream;
+    if (h->pre) h->pre->stream = h->stream;
     return SDR_OK;
 }
 
@@ -594,6 +643,8 @@ struct CallGeom {
     bool use_lds;
     bool mfma;   // k_frontend_mfma: T = 64*nw threads, 256*nw FIR outputs per tile
 };
+
+static void fill_geom_gated(const sdr_handle* h, long long nitems, long long keep_c0, CallGeom& g);
 
 // channel filter (+ demod + slicer unless the output goes to the squelch stage)
 static int launch_front(sdr_handle* h, const float2* x, long long stride, long long n, int ncap,
@@ -654,9 +705,13 @@ static int launch_front(sdr_handle* h, const float2* x, long long stride, long l
         hipLaunchKernelGGL(k_frontend<false>, grid, block, 0, h->stream, P);
     HIPCHK(h, hipGetLastError());
     if (post && !to_squelch) {
+        // the post filter has its own tiling: one output per thread, 256 per tile
+        CallGeom gp;
+        fill_geom_gated(h, g.nout, g.keep_c0, gp);
         PostParams Q;
         memset(&Q, 0, sizeof Q);
         Q.v = h->d_tap;
+        Q.hist = hist ? h->d_post_hist[h->post_hist_sel] : nullptr;  // streaming call
         Q.v_stride = h->tap_stride;
         Q.nout = g.nout;
         Q.ntaps = c.post_ntaps;
@@ -671,10 +726,10 @@ static int launch_front(sdr_handle* h, const float2* x, long long stride, long l
         Q.tap = h->d_tap2;
         Q.tap_stride = h->tap_stride;
         Q.tsum = h->d_tsum;
-        Q.tiles_per_capture = g.tiles;
-        Q.tile_out = g.tile_out;
-        size_t lds = (size_t)(g.T + c.post_ntaps) * sizeof(float);
-        hipLaunchKernelGGL(k_post_fir_slice, grid, block, lds, h->stream, Q);
+        Q.tiles_per_capture = gp.tiles;
+        Q.tile_out = gp.tile_out;
+        size_t lds = (size_t)(gp.T + c.post_ntaps) * sizeof(float);
+        hipLaunchKernelGGL(k_post_fir_slice, dim3(gp.tiles, ncap), dim3(gp.T), lds, h->stream, Q);
         HIPCHK(h, hipGetLastError());
     }
     return SDR_OK;
@@ -763,6 +818,12 @@ static int launch_front_and_back(sdr_handle* h, const float2* x, long long strid
     Bp.tsum = g.nout > 0 ? h->d_tsum : nullptr;
     Bp.tiles_per_capture = g.tiles;
     Bp.tile_out = g.tile_out;
+    if (post) {  // the slicer ran in k_post_fir_slice with its own tiling
+        CallGeom gp;
+        fill_geom_gated(h, g.nout, g.keep_c0, gp);
+        Bp.tiles_per_capture = gp.tiles;
+        Bp.tile_out = gp.tile_out;
+    }
     Bp.nout = g.nout;
     Bp.nout_var = (h->squelch_on && fresh) ? h->d_sq_cnt : nullptr;
     Bp.keep_n = c.keep_n;
@@ -840,6 +901,18 @@ extern "C" int sdr_batch_process(sdr_handle* h, const void* iq, size_t n, size_t
                                  int is_dev, sdr_out* out)
 {
     if (!h || !iq || ncap < 1) return fail(h, SDR_E_ARG, "sdr_batch_process: bad argument");
+    if (h->pre) {
+        // upstream stage first; this stage then reads its complex output rows in place
+        if (ncap > h->cfg.max_batch) return fail(h, SDR_E_CAPACITY, "sdr_batch_process: batch larger than the handle was created for");
+        int r = sdr_batch_process(h->pre, iq, n, stride, ncap, is_dev, nullptr);
+        if (r) return fail(h, r, "prefilter: " + h->pre->err);
+        sdr_handle* keep = h->pre;
+        h->pre = nullptr;
+        r = sdr_batch_process(h, keep->d_tap, (size_t)keep->last_nout, (size_t)(keep->tap_stride / 2), ncap, 1, out);
+        h->pre = keep;
+        if (r == SDR_OK && out) out->n_in = (uint64_t)n * ncap;
+        return r;
+    }
     if (ncap > h->cfg.max_batch || n > h->cfg.max_samples)
         return fail(h, SDR_E_CAPACITY, "sdr_batch_process: batch larger than the handle was created for");
     if (stride < n) return fail(h, SDR_E_ARG, "sdr_batch_process: stride < n_per_capture");
@@ -913,9 +986,17 @@ static int stream_decode_step(sdr_handle* h, const CallGeom& g, const float2* x,
 extern "C" int sdr_process_iq(sdr_handle* h, const void* iq, size_t n, int is_dev, sdr_out* out)
 {
     if (!h || (!iq && n)) return fail(h, SDR_E_ARG, "sdr_process_iq: bad argument");
+    if (h->pre) {
+        int r = sdr_process_iq(h->pre, iq, n, is_dev, nullptr);
+        if (r) return fail(h, r, "prefilter: " + h->pre->err);
+        sdr_handle* keep = h->pre;
+        h->pre = nullptr;
+        r = sdr_process_iq(h, keep->d_tap, (size_t)keep->last_nout, 1, out);
+        h->pre = keep;
+        if (r == SDR_OK && out) out->n_in = n;
+        return r;
+    }
     if (n > h->cfg.max_samples) return fail(h, SDR_E_CAPACITY, "sdr_process_iq: chunk larger than max_samples");
-    if (h->cfg.post_ntaps > 0)
-        return fail(h, SDR_E_ARG, "post-demod filter chains are batch-only in this version");
     (void)hipSetDevice(h->device);
     const sdr_chain_cfg& c = h->cfg;
     const float2* x = (const float2*)iq;
@@ -958,6 +1039,19 @@ extern "C" int sdr_process_iq(sdr_handle* h, const void* iq, size_t n, int is_de
             HIPCHK(h, hipMemcpyAsync(nxt + (H - n), x, n * sizeof(float2), hipMemcpyDeviceToDevice, h->stream));
         }
         h->hist_sel ^= 1;
+    }
+    // history of the post-demod filter: last post_ntaps-1 demodulated floats
+    if (c.post_ntaps > 1 && nout > 0) {
+        const long long Hp = c.post_ntaps - 1;
+        float* cur = h->d_post_hist[h->post_hist_sel];
+        float* nxt = h->d_post_hist[h->post_hist_sel ^ 1];
+        if (nout >= Hp)
+            HIPCHK(h, hipMemcpyAsync(nxt, h->d_tap + (nout - Hp), (size_t)Hp * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+        else {
+            HIPCHK(h, hipMemcpyAsync(nxt, cur + nout, (size_t)(Hp - nout) * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+            HIPCHK(h, hipMemcpyAsync(nxt + (Hp - nout), h->d_tap, (size_t)nout * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+        }
+        h->post_hist_sel ^= 1;
     }
     // counters
     h->in_count = A + n;

@@ -247,6 +247,46 @@ def test_tfa_analyzer2_chain():
         assert gf.packet() == p
 
 
+def test_tfa_analyzer2_chain_streaming():
+    """The same flowgraph fed in ragged work() chunks: the fff filter's history, the
+    threshold bit and the decoder's rawBuffer carry over; floats, bits and frames
+    equal the one-shot oracle."""
+    fs = 2e6
+    rng = np.random.default_rng(31)
+    pkts, sym = [], []
+    for _ in range(2):
+        p = synth.tfa_packet(ident=int(rng.integers(0, 65536)), temp_c=float(rng.integers(-300, 500)) / 10,
+                             humidity=int(rng.integers(0, 100)))
+        pkts.append(p)
+        sym += synth.tfa_symbols(synth.tfa_bits(p), rng, reset_gap_us=4000.0)
+    env = synth.envelope(sym, fs, lead_in_us=800.0)
+    env = np.concatenate([env, np.zeros(9000, np.uint8)])
+    iq = synth.ook_iq(env, fs, f_off=500e3, amp=0.9, sigma=0.01, rng=rng)
+    post = chain.low_pass(1.0, fs, 500e3, 1e6, chain.WIN_BLACKMAN)
+    y = odsp.freq_xlating_fir(iq, [1.0], 500e3, fs, 1)
+    wv = odsp.fir_fff(odsp.mag2(y), post, 1)
+    wb, _, _ = odsp.slice_bits(wv, 1.0, 0.2, 0.4, 1)
+    cuts = [0, 3, 4, 5, 2000, 2001, 9000, iq.size // 2, iq.size // 2 + 2, iq.size]
+    o = odec.TFAStreamDecoder(sample_rate=2000000, nan_guard=True)
+    got_v, got_b, frames = [], [], []
+    with chain.Chain(fs, decim=1, center_freq=500e3, demod=chain.DEMOD_MAG2, demod_gain=1.0, thr=(0.2, 0.4),
+                     keep_n=1, post_taps=post, tap_demod=True, decoder=chain.DEC_TFA_GRC, max_samples=iq.size) as c:
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            c.process_iq(iq[a:b])
+            got_v.append(c.fetch_demod())
+            got_b.append(c.fetch_bits())
+            frames += c.fetch_frames()
+            o.work([wb[a:b]])
+            st = c.decoder_state()
+            assert st[0] == (1 if o.state == "frame" else 0) and st[3] == o.chunk_id
+    assert _assert_float_parity(np.concatenate(got_v), wv) == 0
+    assert np.array_equal(np.concatenate(got_b), wb)
+    assert len(frames) == len(o.frames) == 2
+    for of, gf, p in zip(o.frames, frames, pkts):
+        assert_tfa_equal(of, gf)
+        assert gf.packet() == p
+
+
 def test_rule_decoders_from_iq(kat):
     """configs[3] emitters: somfy / berner / mumbi envelopes -> IQ -> chain -> frames."""
     fs = 1e6
@@ -342,3 +382,47 @@ def test_tfa_stream_chunked_on_gpu():
     for of, gf, p in zip(o.frames, frames, pkts):
         assert_tfa_equal(of, gf)
         assert gf.packet() == p
+
+
+def test_mumbi_fs300_two_stage_chain(kat):
+    """mumbi/FS300.grc:3157-3242: LPF(100k, 97 taps) -> rational_resampler 1/10 (329 taps)
+    -> mag^2 -> threshold .1/.4 -> slicer -> keep_one_in_n(20).  Two cascaded channel
+    filters (sdr_set_prefilter); floats and bits equal the block-by-block oracle, batch
+    and streaming; with keep 2 (100 kHz) the mumbi rule decodes the code."""
+    fs = 2e6
+    rng = np.random.default_rng(77)
+    code = bytes(kat["mumbi_codes"]["c_on"])
+    sym = synth.mumbi_symbols(code, repeats=3)
+    env = synth.envelope(sym, fs, lead_in_us=9000.0)
+    iq = synth.ook_iq(env, fs, amp=0.9, sigma=0.02, rng=rng)
+    lpf = chain.low_pass(1.0, fs, 100e3, 50e3)
+    rs = chain.resampler_taps(1, 10)
+    assert (lpf.size, rs.size) == (97, 329)
+    y1 = odsp.fir_ccf(iq, lpf, 1)
+    y2 = odsp.resample(y1, rs, 1, 10)
+    assert np.array_equal(y2.view(np.uint32), odsp.fir_ccf(y1, rs, 10).view(np.uint32)[:2 * y2.size])
+    wv = odsp.mag2(y2)
+    for keep_n in (20, 2):
+        wb, _, _ = odsp.slice_bits(wv, 1.0, 0.1, 0.4, keep_n)
+        with chain.Chain(fs, pre_taps=lpf, pre_decim=1, decim=10, taps=rs, demod=chain.DEMOD_MAG2, thr=(0.1, 0.4),
+                         keep_n=keep_n, tap_demod=True, decoder=chain.DEC_MUMBI, max_samples=iq.size) as c:
+            c.batch_process(iq[None, :])
+            v, bits, frames = c.fetch_demod(), c.fetch_bits(), c.fetch_frames()
+            assert _assert_float_parity(v, wv[:v.size]) == 0 and v.size == iq.size // 10
+            assert np.array_equal(bits, wb[:bits.size])
+            if keep_n == 2:
+                o = odec.MumbiSniffer()
+                for lvl, tick in odec.edges_to_events(wb, fs / 10 / keep_n, 8000):
+                    o.cbf(lvl, tick)
+                assert [f.packet() for f in frames] == o.frames and code in o.frames
+        # streaming, ragged chunks (both stages keep their own history)
+        with chain.Chain(fs, pre_taps=lpf, pre_decim=1, decim=10, taps=rs, demod=chain.DEMOD_MAG2, thr=(0.1, 0.4),
+                         keep_n=keep_n, tap_demod=True, max_samples=iq.size) as c:
+            cuts = [0, 7, 8, 5000, 5003, 40000, iq.size]
+            gv, gb = [], []
+            for a, b in zip(cuts[:-1], cuts[1:]):
+                c.process_iq(iq[a:b])
+                gv.append(c.fetch_demod())
+                gb.append(c.fetch_bits())
+            assert _assert_float_parity(np.concatenate(gv), wv[:iq.size // 10]) == 0
+            assert np.array_equal(np.concatenate(gb), wb[:sum(x.size for x in gb)])
