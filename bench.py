@@ -288,7 +288,10 @@ def main():
             x = iq[i].cpu().numpy().view(np.complex64).reshape(-1)
             want = odsp.ook_chain(x, taps, DECIM, 1.0, 0.05, 0.15, 1, fc=F_OFF, fs=FS)
             if not np.array_equal(bits[i], want):
-                raise SystemExit("capture %d: sliced bits differ from the oracle" % i)
+                bad = np.flatnonzero(bits[i] != want)
+                raise SystemExit("capture %d: sliced bits differ from the oracle at %d of %d positions (first %s; "
+                                 "ones: got %d, oracle %d)"
+                                 % (i, bad.size, want.size, bad[:8].tolist(), int(bits[i].sum()), int(want.sum())))
             d = odec.TS33CStreamDecoder(sample_rate=20000)
             d.work([want])
             if [f["packet"] for f in d.frames] != got.get(i):

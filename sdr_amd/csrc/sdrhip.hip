@@ -49,6 +49,8 @@ struct sdr_handle {
     long long bits_stride = 0;
     float* d_tap = nullptr;       // demod floats (or complex pairs)
     float* d_tap2 = nullptr;      // post-filter output
+    unsigned char* d_pack = nullptr;  // rows_to_host staging
+    size_t pack_cap = 0;
     float* d_post_hist[2] = {nullptr, nullptr};  // streaming history of the post-demod filter
     int post_hist_sel = 0;
     long long tap_stride = 0;
@@ -392,7 +394,7 @@ extern "C" int sdr_destroy(sdr_handle* h)
     void* ptrs[] = {h->d_rtaps, h->d_post_rtaps, h->d_nco_tab, h->d_atan_tab, h->d_pow, h->d_log2, h->d_iq,
                     h->d_hist[0], h->d_hist[1], h->d_bits, h->d_tap, h->d_tap2, h->d_tsum, h->d_runs,
                     h->d_cur, h->d_st, h->d_frames, h->d_sq_y, h->d_sq_z, h->d_sq_cnt, h->d_sq_st,
-                    h->d_post_hist[0], h->d_post_hist[1]};
+                    h->d_post_hist[0], h->d_post_hist[1], h->d_pack};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (hipEvent_t e : h->pev) (void)hipEventDestroy(e);
@@ -1084,6 +1086,45 @@ extern "C" int sdr_process_bits(sdr_handle* h, const int8_t* bits, size_t n, int
 }
 
 // ------------------------------------------------------------------ results
+// Rows of a pitched device buffer -> a dense host array.  Not hipMemcpy2D: under
+// rocprofv3 --kernel-trace on ROCm 7.2 its device-to-host form returned without
+// delivering the data (every fetch read zeros).  Rows are packed on the device,
+// then moved with one plain hipMemcpy.
+__global__ void k_pack_rows(const unsigned char* __restrict__ src, size_t spitch, size_t width, size_t rows,
+                            unsigned char* __restrict__ dst)
+{
+    const size_t total = width * rows;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = i / width, c = i - r * width;
+        dst[i] = src[r * spitch + c];
+    }
+}
+
+static int rows_to_host(sdr_handle* h, void* dst, const void* src, size_t spitch, size_t width, size_t rows)
+{
+    if (rows == 0 || width == 0) return SDR_OK;
+    if (rows == 1 || spitch == width) {
+        HIPCHK(h, hipMemcpy(dst, src, width * rows, hipMemcpyDeviceToHost));
+        return SDR_OK;
+    }
+    const size_t total = width * rows;
+    if (total > h->pack_cap) {
+        if (h->d_pack) (void)hipFree(h->d_pack);
+        h->d_pack = nullptr;
+        h->pack_cap = 0;
+        HIPCHK(h, dev_alloc((void**)&h->d_pack, total));
+        h->pack_cap = total;
+    }
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_pack_rows, dim3((unsigned)blocks), dim3(256), 0, h->stream, (const unsigned char*)src, spitch,
+                       width, rows, h->d_pack);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpy(dst, h->d_pack, total, hipMemcpyDeviceToHost));
+    return SDR_OK;
+}
+
 extern "C" int sdr_fetch_frames(sdr_handle* h, sdr_frame* outp, size_t cap, size_t* n)
 {
     if (!h || !n) return fail(h, SDR_E_ARG, "sdr_fetch_frames: bad argument");
@@ -1120,9 +1161,8 @@ extern "C" int sdr_fetch_bits(sdr_handle* h, int8_t* outp, size_t cap, size_t* n
     const size_t total = (size_t)h->last_ncap * (size_t)h->last_nb;
     *n = total;
     if (!outp || cap < total || total == 0) return SDR_OK;
-    HIPCHK(h, hipMemcpy2D(outp, (size_t)h->last_nb, h->d_bits + h->last_bits_off, (size_t)h->bits_stride,
-                          (size_t)h->last_nb, (size_t)h->last_ncap, hipMemcpyDeviceToHost));
-    return SDR_OK;
+    return rows_to_host(h, outp, h->d_bits + h->last_bits_off, (size_t)h->bits_stride, (size_t)h->last_nb,
+                        (size_t)h->last_ncap);
 }
 
 extern "C" int sdr_fetch_demod(sdr_handle* h, float* outp, size_t cap, size_t* n)
@@ -1136,9 +1176,7 @@ extern "C" int sdr_fetch_demod(sdr_handle* h, float* outp, size_t cap, size_t* n
     *n = total;
     if (!outp || cap < total || total == 0) return SDR_OK;
     const float* src = (h->cfg.post_ntaps > 0 && h->d_tap2) ? h->d_tap2 : h->d_tap;
-    HIPCHK(h, hipMemcpy2D(outp, w * sizeof(float), src, (size_t)h->tap_stride * sizeof(float), w * sizeof(float),
-                          (size_t)h->last_ncap, hipMemcpyDeviceToHost));
-    return SDR_OK;
+    return rows_to_host(h, outp, src, (size_t)h->tap_stride * sizeof(float), w * sizeof(float), (size_t)h->last_ncap);
 }
 
 extern "C" int sdr_fetch_squelch_counts(sdr_handle* h, int32_t* outp, size_t cap, size_t* n)
