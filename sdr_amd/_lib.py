@@ -141,6 +141,30 @@ EXPORTS = [
 _lib = None
 
 
+def _share_torch_hip_runtime():
+    """PyTorch-ROCm ships its own libamdhip64.so (same SONAME as /opt/rocm's).  If
+    libsdrhip pulled in the system copy first, a later `import torch` would load a
+    second HIP runtime into the process and fail with "No HIP GPUs are available".
+    Loading torch's copy first (by path, torch itself is not imported) makes both
+    bind to one runtime, whichever is used first."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if spec is None or not spec.submodule_search_locations:
+        return
+    path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(path):
+        try:
+            C.CDLL(path, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load():
     """Load libsdrhip.so; raises if it has not been built (no CPU fallback)."""
     global _lib
@@ -149,6 +173,7 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise ImportError("%s not found: build it with __graft_entry__.build() "
                           "(hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH)
+    _share_torch_hip_runtime()
     L = C.CDLL(LIB_PATH)
     H = C.c_void_p
     fp = C.POINTER(C.c_float)
