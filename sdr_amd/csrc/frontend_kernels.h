@@ -163,16 +163,25 @@ __global__ void __launch_bounds__(256) k_frontend(FrontParams P)
         const int odd = (int)(gidx & 1);
         const long long lo_al = lo_idx - odd;
         const int pairs = (count + odd + 1) >> 1;
-        const bool interior = P.vec_ok && !P.pre_tab && lo_al >= 0 && (lo_al + 2LL * pairs) <= P.n;
-        if (interior) {
+        if (P.vec_ok && !P.pre_tab) {
+            // Every 16-B chunk that lies inside the capture goes by DMA; only the few
+            // chunks that touch the capture's edges (zero padding / streaming history)
+            // are fetched by their lanes with guarded loads.  (First and last tile of a
+            // capture used to take a fully guarded, serialised staging loop.)
             lsh = odd;
-            const float2* src = x + lo_al;
             for (int p0 = (threadIdx.x & ~63); p0 < pairs; p0 += T) {
                 const int p = p0 + lane_id();
-                if (p < pairs)
-                    __builtin_amdgcn_global_load_lds(
-                        (const __attribute__((address_space(1))) void*)(src + 2 * p),
-                        (__attribute__((address_space(3))) void*)(lds + 2 * p0), 16, 0, 0);
+                if (p < pairs) {
+                    const long long s = lo_al + 2LL * p;
+                    if (s >= 0 && s + 2 <= P.n)
+                        __builtin_amdgcn_global_load_lds(
+                            (const __attribute__((address_space(1))) void*)(x + s),
+                            (__attribute__((address_space(3))) void*)(lds + 2 * p0), 16, 0, 0);
+                    else {
+                        lds[2 * p] = fetch(s);
+                        lds[2 * p + 1] = fetch(s + 1);
+                    }
+                }
             }
         } else if (P.pre_tab) {
             // freq_xlating_fir_filter with taps=[1] in front of the FIR: rotate

@@ -147,19 +147,26 @@ __global__ void __launch_bounds__(256) k_frontend_mfma(FrontParams P)
     int odd = (int)(gidx & 1);
     const long long lo_al = lo_idx - odd;
     const int nsrc = (npos + odd + 1) >> 1;                // 16-B source chunks
-    const bool interior = P.vec_ok && !P.pre_tab && lo_al >= 0 && (lo_al + 2LL * nsrc) <= P.n;
-    if (interior) {
+    if (P.vec_ok && !P.pre_tab) {
+        // chunks inside the capture by DMA; the few that touch its edges (zero
+        // padding / streaming history) by guarded loads of their own lanes
         const int per = 8 * D + 1;                         // LDS chunks per pad block (last one is the pad)
         const int nlds = nsrc + nsrc / (8 * D) + 1;
-        const float2* src = x + lo_al;
         for (int c0 = (t & ~63); c0 < nlds; c0 += T) {
             const int c = c0 + lane;
             const int blk = c / per, r = c - blk * per;
             const int sc = blk * 8 * D + r;
-            if (c < nlds && r < 8 * D && sc < nsrc)
-                __builtin_amdgcn_global_load_lds(
-                    (const __attribute__((address_space(1))) void*)(src + 2 * sc),
-                    (__attribute__((address_space(3))) void*)(smp + 4 * c0), 16, 0, 0);
+            if (c < nlds && r < 8 * D && sc < nsrc) {
+                const long long s = lo_al + 2LL * sc;
+                if (s >= 0 && s + 2 <= P.n)
+                    __builtin_amdgcn_global_load_lds(
+                        (const __attribute__((address_space(1))) void*)(x + s),
+                        (__attribute__((address_space(3))) void*)(smp + 4 * c0), 16, 0, 0);
+                else {
+                    *reinterpret_cast<float2*>(smp + 4 * c) = fetch(s);
+                    *reinterpret_cast<float2*>(smp + 4 * c + 2) = fetch(s + 1);
+                }
+            }
         }
     } else {
         odd = 0;
