@@ -136,7 +136,9 @@ __global__ void __launch_bounds__(256) k_frontend(FrontParams P)
     extern __shared__ __align__(16) unsigned char smem_raw[];
     float2* lds = reinterpret_cast<float2*>(smem_raw);
     __shared__ int sh[12];
-    __shared__ float2 ysh[256];
+    // discriminator history exchange: aliases the (by then consumed) tile when there is one
+    __shared__ float2 ysh_static[USE_LDS ? 1 : 256];
+    float2* const ysh = USE_LDS ? lds : ysh_static;
 
     const int T = blockDim.x;
     const int tile = blockIdx.x, cap = blockIdx.y;
@@ -328,6 +330,7 @@ __global__ void __launch_bounds__(256) k_frontend(FrontParams P)
     } else if (P.demod == SDR_DEMOD_MAG2) {
         v = __builtin_fmaf(ar, ar, ai * ai);
     } else {
+        if (USE_LDS) __syncthreads();  // every wave has finished reading the tile
         ysh[t] = make_float2(ar, ai);
         __syncthreads();
         if (valid) {

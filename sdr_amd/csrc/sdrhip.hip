@@ -335,6 +335,11 @@ static void pick_tile(const sdr_handle* h, int& T, size_t& lds, bool& use_lds)
     const int D = h->cfg.decim, nt = h->ntaps;
     const int cands[3] = {256, 128, 64};
     use_lds = true;
+    if (const char* e = getenv("SDR_TILE")) {  // tuning override: 64 | 128 | 256
+        T = atoi(e);
+        lds = ((size_t)(T - 1) * D + nt + 2) * sizeof(float2);
+        if ((T == 64 || T == 128 || T == 256) && lds <= 60 * 1024) return;
+    }
     for (int i = 0; i < 3; ++i) {
         T = cands[i];
         lds = ((size_t)(T - 1) * D + nt + 2) * sizeof(float2);  // +2: 16-B aligned tile start

@@ -1,0 +1,22 @@
+"""Scratch: F-shape front end with forced tile sizes."""
+import os, sys, numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+from sdr_amd import chain
+dev = torch.device("cuda", 0)
+ncap = 1250
+iq = torch.randn((ncap, bench.N_PER_CAPTURE, 2), device=dev, dtype=torch.float32) * 0.1
+taps = chain.low_pass(1.0, bench.FS, 20e3, 40e3)
+for tile in sys.argv[1:]:
+    if tile == "auto":
+        os.environ.pop("SDR_TILE", None)
+    else:
+        os.environ["SDR_TILE"] = tile
+    c = chain.Chain(bench.FS, decim=50, center_freq=bench.F_OFF, taps=taps, decoder=chain.DEC_NONE, max_batch=ncap, max_samples=bench.N_PER_CAPTURE)
+    c.profile_enable(True)
+    for _ in range(14):
+        c.batch_process(iq)
+    f, b = c.profile_read()
+    ms = np.mean(f[2:])
+    print("tile=%s front %.4f ms  %.0f GB/s (%.1f%%)" % (tile, ms, 8.02 * ncap * bench.N_PER_CAPTURE / ms / 1e6, 8.02 * ncap * bench.N_PER_CAPTURE / ms / 1e6 / 80), flush=True)
+    c.close()
