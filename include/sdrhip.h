@@ -221,6 +221,42 @@ SDR_API int sdr_profile_read(sdr_handle* h, float* front_ms, float* back_ms, int
 SDR_API int sdr_export_frames(sdr_handle* h, void* frames_dev, size_t frames_bytes, void* counts_dev,
                               size_t counts_bytes);
 
+/* ---- one long capture in contiguous segments (BASELINE.json north_star: "each
+ * GPU gets a contiguous segment with FIR-history overlap") ----------------------
+ * No counterpart in the reference (GNU Radio streams one capture through one
+ * thread per block); what it must reproduce is the reference's single stream:
+ * the sliced bytes of all segments, concatenated, equal those of one
+ * sdr_process_iq pass over the whole capture (ref: the block chain of
+ * TS33C/live_decoder.grc:3292-3377 run from stream start).
+ *
+ * sdr_seek positions the handle's streaming state (sample/output counters, NCO
+ * phase origin, keep_one_in_n counter, FIR history) as if the first abs_index
+ * samples of the capture had been consumed; `halo` = the n_halo samples that
+ * precede abs_index (the last sdr_history_len(h) of them are used, missing ones
+ * count as the zeros before stream start).  The threshold_ff state is unknown at
+ * that point: it restarts from cfg.thr_init, and sdr_segment_info afterwards says
+ * which leading bytes of the NEXT sdr_process_iq call depended on it.  Decoder
+ * state, rawBuffer and squelch/post-filter state are reset; chains with a
+ * prefilter, a squelch or a post-demod filter are refused (their state is not
+ * a function of the halo alone). */
+SDR_API int sdr_history_len(sdr_handle* h);
+SDR_API int sdr_seek(sdr_handle* h, uint64_t abs_index, const void* halo, size_t n_halo, int is_device_ptr);
+typedef struct sdr_segment_info {
+    uint64_t first_bit_index; /* position in the capture's sliced stream of the last call's first byte */
+    uint64_t n_bits;          /* bytes the last call emitted */
+    uint64_t n_undetermined;  /* leading bytes emitted before the call's first threshold event: their value is the
+                                 state the stream had when the call began (computed here with the handle's carry-in) */
+    int32_t has_event;        /* the call contained a set or clear event */
+    int32_t last_state;       /* threshold_ff state after the call (given the carry-in used) */
+    int32_t carry_in;         /* the carry-in the call was computed with */
+    int32_t pad_;
+} sdr_segment_info;
+/* summary of the last sdr_process_iq call (synchronises) */
+SDR_API int sdr_segment_info_get(sdr_handle* h, sdr_segment_info* info);
+/* the last call's sliced bytes (capture-major, dense) into a caller-owned DEVICE
+ * buffer on the handle's stream, ready for a collective; *n = bytes written. */
+SDR_API int sdr_export_bits(sdr_handle* h, void* bits_dev, size_t cap_bytes, size_t* n);
+
 /* ---- FM-Radio chain (BASELINE.json configs[1]) --------------------------------
  * ref: FM-Radio/FM-Radio.grc:2903-2964 wiring: freq_xlating_fir_filter_ccc
  * (taps 1, center_freq -shift) -> rational_resampler_ccc 1/int(samp_rate/500e3)

@@ -125,6 +125,18 @@ class PreambleInfo(C.Structure):
     ]
 
 
+class SegmentInfo(C.Structure):
+    _fields_ = [
+        ("first_bit_index", C.c_uint64),
+        ("n_bits", C.c_uint64),
+        ("n_undetermined", C.c_uint64),
+        ("has_event", C.c_int32),
+        ("last_state", C.c_int32),
+        ("carry_in", C.c_int32),
+        ("pad_", C.c_int32),
+    ]
+
+
 #: every symbol include/sdrhip.h declares (checked by tests/test_abi.py)
 EXPORTS = [
     "sdr_firdes_low_pass", "sdr_resampler_taps", "sdr_create", "sdr_destroy", "sdr_set_taps",
@@ -136,6 +148,7 @@ EXPORTS = [
     "sdr_preamble_last_error", "sdr_set_prefilter",
     "sdr_fm_create", "sdr_fm_destroy", "sdr_fm_set_stream", "sdr_fm_process", "sdr_fm_fetch",
     "sdr_fm_last_error",
+    "sdr_history_len", "sdr_seek", "sdr_segment_info_get", "sdr_export_bits",
 ]
 
 _lib = None
@@ -227,6 +240,14 @@ def load():
     L.sdr_profile_read.argtypes = [H, fp, fp, C.c_int, C.POINTER(C.c_int)]
     L.sdr_export_frames.restype = C.c_int
     L.sdr_export_frames.argtypes = [H, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    L.sdr_history_len.restype = C.c_int
+    L.sdr_history_len.argtypes = [H]
+    L.sdr_seek.restype = C.c_int
+    L.sdr_seek.argtypes = [H, C.c_uint64, C.c_void_p, C.c_size_t, C.c_int]
+    L.sdr_segment_info_get.restype = C.c_int
+    L.sdr_segment_info_get.argtypes = [H, C.POINTER(SegmentInfo)]
+    L.sdr_export_bits.restype = C.c_int
+    L.sdr_export_bits.argtypes = [H, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.sdr_fm_create.restype = C.c_int
     L.sdr_fm_create.argtypes = [C.POINTER(FmCfg), C.POINTER(H)]
     L.sdr_fm_destroy.restype = C.c_int

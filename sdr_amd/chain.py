@@ -156,6 +156,12 @@ class Chain(object):
         return self.out
 
     def process_bits(self, bits):
+        if _is_torch(bits) and bits.is_cuda:
+            if not bits.is_contiguous() or bits.element_size() != 1:
+                raise ValueError("bit tensor must be contiguous int8/uint8")
+            _lib.check(self._h, self._L.sdr_process_bits(self._h, C.c_void_p(bits.data_ptr()), bits.numel(), 1,
+                                                         C.byref(self.out)))
+            return self.out
         b = np.ascontiguousarray(bits, np.int8)
         _lib.check(self._h, self._L.sdr_process_bits(self._h, C.c_void_p(b.ctypes.data), b.size, 0, C.byref(self.out)))
         return self.out
@@ -195,6 +201,34 @@ class Chain(object):
         if n.value:
             _lib.check(self._h, self._L.sdr_fetch_demod(self._h, C.c_void_p(out.ctypes.data), out.size, C.byref(n)))
         return out.view(np.complex64) if self.cfg.demod == DEMOD_NONE else out
+
+    # -- one long capture in segments (sdr_seek / sdr_segment_info_get)
+    def history_len(self):
+        return int(self._L.sdr_history_len(self._h))
+
+    def seek(self, abs_index, halo=None):
+        """Position the streaming state at sample `abs_index` of a capture; `halo`
+        = the samples that precede it (at least min(abs_index, history_len()))."""
+        if halo is None:
+            _lib.check(self._h, self._L.sdr_seek(self._h, int(abs_index), None, 0, 0))
+            return
+        ptr, dev, keep = self._iq_ptr(halo)
+        n = int(keep.numel() if dev else keep.size)
+        if dev and not keep.is_complex():
+            n //= 2
+        _lib.check(self._h, self._L.sdr_seek(self._h, int(abs_index), C.c_void_p(ptr), n, dev))
+
+    def segment_info(self):
+        info = _lib.SegmentInfo()
+        _lib.check(self._h, self._L.sdr_segment_info_get(self._h, C.byref(info)))
+        return info
+
+    def export_bits(self, bits_tensor):
+        """Last call's sliced bytes into a torch uint8/int8 tensor on this GPU; -> count."""
+        n = C.c_size_t()
+        _lib.check(self._h, self._L.sdr_export_bits(self._h, C.c_void_p(bits_tensor.data_ptr()),
+                                                    bits_tensor.numel() * bits_tensor.element_size(), C.byref(n)))
+        return n.value
 
     def decoder_state(self):
         st = (C.c_int32 * 4)()

@@ -17,6 +17,7 @@ __global__ void __launch_bounds__(BK_THREADS) k_backend(BackParams P)
     __shared__ __align__(16) unsigned char s_C[SDR_CUR_CAP * 8];
     __shared__ int s_cnt[BK_THREADS];
     __shared__ int s_wtot[4];
+    __shared__ int s_fe[4];
     __shared__ unsigned int s_words[64];
     __shared__ unsigned char s_par[256];
     __shared__ unsigned char s_bits[512];
@@ -54,6 +55,7 @@ __global__ void __launch_bounds__(BK_THREADS) k_backend(BackParams P)
             st->gap_short_limit = 775.0;
         }
         st->n_frames = 0;
+        st->first_evt = -1;
     }
     __syncthreads();
 
@@ -63,9 +65,10 @@ __global__ void __launch_bounds__(BK_THREADS) k_backend(BackParams P)
         const int nt = P.tiles_per_capture;
         const int per = (nt + BK_THREADS - 1) / BK_THREADS;
         const int t0 = tid * per, t1 = (t0 + per < nt) ? t0 + per : nt;
-        int has = 0, last = 0;
+        int has = 0, last = 0, myfe = -1;
         for (int i = t0; i < t1; ++i)
             if (ts[i].first_evt >= 0) {
+                if (!has) myfe = ts[i].first_evt;
                 has = 1;
                 last = ts[i].last_state;
             }
@@ -75,7 +78,11 @@ __global__ void __launch_bounds__(BK_THREADS) k_backend(BackParams P)
         if (lane == 0) {
             s_has[wv] = mh != 0;
             s_last[wv] = mh ? (int)((ml >> (63 - __builtin_clzll(mh))) & 1) : 0;
+            if (!mh) s_fe[wv] = -1;
         }
+        // tiles are handed out in ascending order: the call's first event is the
+        // first event of the first thread that saw one
+        if (mh && lane == __builtin_ctzll(mh)) s_fe[wv] = myfe;
         __syncthreads();
         int carry = P.use_state_thr ? st->thr_state : P.thr_init;
         const unsigned long long below = mh & ((1ull << lane) - 1ull);
@@ -108,7 +115,13 @@ __global__ void __launch_bounds__(BK_THREADS) k_backend(BackParams P)
         // thread 0 is the only writer of *st
         if ((t0 < nt && t1 == nt) || (nt == 0 && tid == 0)) s_cnt[0] = carry;
         __syncthreads();
-        if (tid == 0) st->thr_state = s_cnt[0];
+        if (tid == 0) {
+            st->thr_state = s_cnt[0];
+            int fe = -1;
+            for (int w = 3; w >= 0; --w)
+                if (s_fe[w] >= 0) fe = s_fe[w];
+            st->first_evt = fe;
+        }
     }
     if (!run_decoder || P.decoder == SDR_DEC_NONE) return;
     __syncthreads();

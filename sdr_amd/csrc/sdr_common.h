@@ -24,7 +24,7 @@ struct DecState {
     int32_t thr_state;      // threshold_ff state carried between streaming calls
     int32_t n_frames;       // frames written by the last call
     int32_t overflow;       // !=0: runs/frames/symbol table overflow
-    int32_t pad_;
+    int32_t first_evt;      // demod-output index (within the last call) of its first threshold event, -1 if none (sdr_segment_info)
     double pulse_short_limit;
     double gap_short_limit;
 };

@@ -88,6 +88,9 @@ struct sdr_handle {
     // last call
     int last_ncap = 0;
     long long last_nb = 0, last_nout = 0, last_bits_off = 0;
+    long long last_keep_c0 = 0;
+    unsigned long long last_out0 = 0;   // absolute output index of the last call's output 0
+    int carry_next = 0, carry_last = -1; // threshold_ff carry-in of the next / last streaming call as far as the host knows it (-1 unknown)
     double dec_rate = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // per-launch profiling ring
@@ -382,7 +385,22 @@ static bool pick_mfma(const sdr_handle* h, int& T, size_t& lds)
 }
 
 // ------------------------------------------------------------------ create
-extern "C" int sdr_version(void) { return 100; }
+extern "C" int sdr_version(void) { return 101; }
+
+// stream 0's decoder object as StreamDecoder.__init__ leaves it, threshold_ff at its init value
+static int reset_dec_state(sdr_handle* h)
+{
+    DecState s0;
+    memset(&s0, 0, sizeof s0);
+    s0.thr_state = h->cfg.thr_init;
+    s0.first_evt = -1;
+    s0.pulse_short_limit = 775.0;
+    s0.gap_short_limit = 775.0;
+    HIPCHK(h, hipMemcpy(h->d_st, &s0, sizeof s0, hipMemcpyHostToDevice));
+    h->carry_next = h->cfg.thr_init;
+    h->carry_last = -1;
+    return SDR_OK;
+}
 
 extern "C" const char* sdr_last_error(sdr_handle* h) { return h ? h->err.c_str() : g_err.c_str(); }
 
@@ -485,12 +503,8 @@ extern "C" int sdr_create(const sdr_chain_cfg* cfg, sdr_handle** out)
         HIPCHK(h, dev_alloc((void**)&h->d_st, (size_t)B * sizeof(DecState)));
         HIPCHK(h, hipMemset(h->d_st, 0, (size_t)B * sizeof(DecState)));
         {
-            DecState s0;
-            memset(&s0, 0, sizeof s0);
-            s0.thr_state = h->cfg.thr_init;
-            s0.pulse_short_limit = 775.0;
-            s0.gap_short_limit = 775.0;
-            HIPCHK(h, hipMemcpy(h->d_st, &s0, sizeof s0, hipMemcpyHostToDevice));
+            int r2 = reset_dec_state(h);
+            if (r2) return r2;
         }
         HIPCHK(h, dev_alloc((void**)&h->d_frames, (size_t)(B * h->cfg.max_frames) * sizeof(sdr_frame)));
         h->keep_ctr = h->cfg.keep_n;
@@ -956,6 +970,8 @@ extern "C" int sdr_batch_process(sdr_handle* h, const void* iq, size_t n, size_t
     h->last_nb = g.ne;
     h->last_nout = g.nout;
     h->last_bits_off = 0;
+    h->last_keep_c0 = g.keep_c0;
+    h->last_out0 = 0;
     return finish_out(h, out, (unsigned long long)n * ncap, g.ne);
 }
 
@@ -1034,6 +1050,10 @@ extern "C" int sdr_process_iq(sdr_handle* h, const void* iq, size_t n, int is_de
     }
     r = stream_decode_step(h, g, x, (long long)n, true, out, n);
     if (r) return r;
+    h->last_keep_c0 = g.keep_c0;
+    h->last_out0 = h->out_count;
+    h->carry_last = h->carry_next;
+    h->carry_next = -1;
     // history for the next call: last hist_len samples of (hist ++ x)
     if (n) {
         const int H = h->hist_len;
@@ -1272,6 +1292,80 @@ extern "C" int sdr_export_frames(sdr_handle* h, void* frames_dev, size_t frames_
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(k_export_frames, dim3(blocks), dim3(256), 0, h->stream, h->d_frames, h->d_st, B,
                        h->cfg.max_frames, (sdr_frame*)frames_dev, (int32_t*)counts_dev);
+    HIPCHK(h, hipGetLastError());
+    return SDR_OK;
+}
+
+// ------------------------------------------------------------------ segments
+extern "C" int sdr_history_len(sdr_handle* h) { return h ? h->hist_len : SDR_E_ARG; }
+
+extern "C" int sdr_seek(sdr_handle* h, uint64_t abs_index, const void* halo, size_t n_halo, int is_dev)
+{
+    if (!h) return fail(h, SDR_E_ARG, "sdr_seek: null handle");
+    if (h->pre || h->squelch_on || h->cfg.post_ntaps > 0 || h->prerotate)
+        return fail(h, SDR_E_ARG, "sdr_seek: chains with a prefilter, squelch or post-demod filter cannot be positioned from a halo");
+    const size_t H = (size_t)h->hist_len;
+    const size_t need = abs_index < H ? (size_t)abs_index : H;
+    if (n_halo < need || (need && !halo))
+        return fail(h, SDR_E_ARG, "sdr_seek: halo shorter than min(abs_index, sdr_history_len)");
+    (void)hipSetDevice(h->device);
+    float2* cur = h->d_hist[h->hist_sel];
+    HIPCHK(h, hipMemsetAsync(cur, 0, (size_t)h->hist_cap * sizeof(float2), h->stream));
+    if (need)
+        HIPCHK(h, hipMemcpyAsync(cur + (H - need), (const float2*)halo + (n_halo - need), need * sizeof(float2),
+                                 is_dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const unsigned long long D = (unsigned long long)h->cfg.decim, kn = (unsigned long long)h->cfg.keep_n;
+    h->in_count = abs_index;
+    h->out_count = abs_index / D;  // outputs are emitted once D items are consumed
+    h->keep_ctr = (long long)(kn - (h->out_count % kn));
+    h->raw_n = 0;
+    h->last_ncap = 0;
+    h->last_nb = h->last_nout = h->last_bits_off = 0;
+    return reset_dec_state(h);
+}
+
+extern "C" int sdr_segment_info_get(sdr_handle* h, sdr_segment_info* info)
+{
+    if (!h || !info) return fail(h, SDR_E_ARG, "sdr_segment_info_get: null argument");
+    (void)hipSetDevice(h->device);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    DecState s;
+    HIPCHK(h, hipMemcpy(&s, h->d_st, sizeof s, hipMemcpyDeviceToHost));
+    memset(info, 0, sizeof *info);
+    const long long kn = h->cfg.keep_n, nb = h->last_nb, c0 = h->last_keep_c0;
+    info->n_bits = (uint64_t)nb;
+    info->first_bit_index = (uint64_t)((h->last_out0 + (unsigned long long)c0 + 1ull) / (unsigned long long)kn) - 1ull;
+    long long und = nb;
+    if (s.first_evt >= 0) {
+        und = s.first_evt <= c0 ? 0 : ((long long)s.first_evt - c0 + kn - 1) / kn;
+        if (und > nb) und = nb;
+    }
+    info->n_undetermined = (uint64_t)und;
+    info->has_event = s.first_evt >= 0;
+    info->last_state = s.thr_state;
+    info->carry_in = h->carry_last;
+    if (h->carry_next < 0) h->carry_next = s.thr_state;
+    return SDR_OK;
+}
+
+extern "C" int sdr_export_bits(sdr_handle* h, void* bits_dev, size_t cap_bytes, size_t* n)
+{
+    if (!h || !n) return fail(h, SDR_E_ARG, "sdr_export_bits: null argument");
+    const size_t rows = (size_t)h->last_ncap, width = (size_t)h->last_nb, total = rows * width;
+    *n = total;
+    if (total == 0) return SDR_OK;
+    if (!bits_dev || cap_bytes < total) return fail(h, SDR_E_CAPACITY, "sdr_export_bits: destination too small");
+    (void)hipSetDevice(h->device);
+    const int8_t* src = h->d_bits + h->last_bits_off;
+    if (rows == 1 || (size_t)h->bits_stride == width) {
+        HIPCHK(h, hipMemcpyAsync(bits_dev, src, total, hipMemcpyDeviceToDevice, h->stream));
+        return SDR_OK;
+    }
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_pack_rows, dim3((unsigned)blocks), dim3(256), 0, h->stream, (const unsigned char*)src,
+                       (size_t)h->bits_stride, width, rows, (unsigned char*)bits_dev);
     HIPCHK(h, hipGetLastError());
     return SDR_OK;
 }
