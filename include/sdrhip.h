@@ -47,6 +47,12 @@ enum {
     SDR_DEMOD_QUAD = 2  /* analog_quadrature_demod_cf (ref: TFA/decoder.grc:450-481) */
 };
 
+/* sample format of the IQ input (sdr_set_input_format) */
+enum {
+    SDR_IN_FC32 = 0, /* complex64, what every GNU Radio block of the reference exchanges */
+    SDR_IN_CU8 = 1   /* rtl-sdr bytes (u8 I, u8 Q), converted as rtlsdr_source does: (u8 - 127.4) / 128 */
+};
+
 /* bit decoder fed by the sliced stream */
 enum {
     SDR_DEC_NONE = 0,
@@ -148,6 +154,15 @@ SDR_API int sdr_set_post_taps(sdr_handle* h, const float* taps, int n);
  * cfg.sample_rate / cfg.max_samples of the chain then refer to the stream BETWEEN
  * the two stages; sdr_process_iq / sdr_batch_process take the upstream input. */
 SDR_API int sdr_set_prefilter(sdr_handle* h, const float* taps, int n, int decim);
+/* Input sample format, SDR_IN_*.  SDR_IN_CU8 = the rtl-sdr on-disk/USB format:
+ * what `rtlsdr_source` (ref: TS33C/live_decoder.grc:3292 wiring, block rtlsdr_source_0)
+ * receives from the dongle and what the READMEs record (`rtl_sdr -s 2048000
+ * sample.cu8`, ref: berner/README.md:21, mumbi/README.md:20); the conversion
+ * (u8 - 127.4) / 128 per component happens while the tile is staged, so the chain
+ * reads 2 bytes per sample instead of 8.  iq pointers, strides and halos of every
+ * entry point then count (I,Q) byte pairs.  Resets the streaming state.  With a
+ * prefilter the format applies to the upstream stage's input. */
+SDR_API int sdr_set_input_format(sdr_handle* h, int fmt);
 /* analog_pwr_squelch_cc (ramp 0) between the channel filter and the demodulator:
  * p = alpha*|y|^2 + (1-alpha)*p (double), an item passes iff !(p < 10^(db/10));
  * gate != 0 drops muted items (the stream gets shorter), gate == 0 zeroes them.

@@ -263,6 +263,14 @@ def resample(x, taps, L, M, hist=None):
     return y[:k].copy()
 
 
+def cu8_to_fc32(u8):
+    """rtlsdr_source's conversion of the dongle's bytes [GR-ext: gr-osmosdr
+    lib/rtl/rtl_source_c.cc lookup table, unpinned]: (float(u8) - 127.4f) * (1/128)
+    per component.  u8: (..., 2) or flat interleaved I,Q -> complex64."""
+    f = (np.asarray(u8, np.uint8).astype(np.float32) - np.float32(127.4)) * np.float32(1.0 / 128.0)
+    return np.ascontiguousarray(f.reshape(-1, 2)).view(np.complex64).reshape(-1)
+
+
 def ook_chain(iq, taps, D, gain, lo, hi, keep_n, fc=0.0, fs=1.0, return_mag=False):
     """Whole OOK chain from stream start; taps real (fc==0) or translated (fc!=0)."""
     xf = _c2f(iq)

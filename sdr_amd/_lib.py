@@ -12,6 +12,7 @@ SDR_OK, SDR_E_ARG, SDR_E_HIP, SDR_E_CAPACITY, SDR_E_OVERFLOW, SDR_E_NODEVICE = 0
 
 WIN_HAMMING, WIN_HANN, WIN_BLACKMAN, WIN_RECTANGULAR, WIN_KAISER, WIN_BLACKMAN_HARRIS = range(6)
 DEMOD_NONE, DEMOD_MAG2, DEMOD_QUAD = 0, 1, 2
+IN_FC32, IN_CU8 = 0, 1
 DEC_NONE, DEC_TS33C, DEC_TFA, DEC_TFA_GRC, DEC_SOMFY, DEC_BERNER, DEC_MUMBI = range(7)
 
 FRAME_OK = 0
@@ -148,7 +149,7 @@ EXPORTS = [
     "sdr_preamble_last_error", "sdr_set_prefilter",
     "sdr_fm_create", "sdr_fm_destroy", "sdr_fm_set_stream", "sdr_fm_process", "sdr_fm_fetch",
     "sdr_fm_last_error",
-    "sdr_history_len", "sdr_seek", "sdr_segment_info_get", "sdr_export_bits",
+    "sdr_set_input_format", "sdr_history_len", "sdr_seek", "sdr_segment_info_get", "sdr_export_bits",
 ]
 
 _lib = None
@@ -240,6 +241,8 @@ def load():
     L.sdr_profile_read.argtypes = [H, fp, fp, C.c_int, C.POINTER(C.c_int)]
     L.sdr_export_frames.restype = C.c_int
     L.sdr_export_frames.argtypes = [H, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    L.sdr_set_input_format.restype = C.c_int
+    L.sdr_set_input_format.argtypes = [H, C.c_int]
     L.sdr_history_len.restype = C.c_int
     L.sdr_history_len.argtypes = [H]
     L.sdr_seek.restype = C.c_int

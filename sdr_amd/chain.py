@@ -44,13 +44,16 @@ class Chain(object):
     def __init__(self, sample_rate, decim=1, center_freq=0.0, taps=None, demod=DEMOD_MAG2, demod_gain=1.0,
                  thr=(0.05, 0.15), thr_init=0, keep_n=1, decoder=DEC_NONE, decoder_rate=0.0, post_taps=None,
                  tap_demod=False, max_batch=1, max_frames=16, max_samples=1 << 20, squelch=None,
-                 pre_taps=None, pre_decim=1):
+                 pre_taps=None, pre_decim=1, input_format="fc32"):
         """squelch=(threshold_db, alpha[, gate=True]): analog_pwr_squelch_cc between the channel
         filter and the demodulator (TFA/decoder.grc:391-446).
         pre_taps/pre_decim: an upstream fir_filter_ccf in front of this chain's own filter
         (mumbi/FS300.grc: low_pass_filter -> rational_resampler 1/10); sample_rate and
-        max_samples are then those of the upstream input."""
+        max_samples are then those of the upstream input.
+        input_format: "fc32" (complex64) or "cu8" (rtl-sdr bytes, uint8 I/Q pairs converted as
+        rtlsdr_source does; arrays of shape (..., n, 2) or (..., 2n) uint8)."""
         self._L = _lib.load()
+        self._cu8 = {"fc32": False, "cu8": True}[input_format]
         self._h = C.c_void_p()
         cfg = _lib.ChainCfg()
         pre_decim = int(pre_decim) if pre_taps is not None else 1
@@ -87,6 +90,8 @@ class Chain(object):
                                                           pre_decim))
         if squelch is not None:
             self.set_squelch(*squelch)
+        if self._cu8:
+            _lib.check(self._h, self._L.sdr_set_input_format(self._h, _lib.IN_CU8))
 
     def set_squelch(self, threshold_db, alpha, gate=True):
         _lib.check(self._h, self._L.sdr_set_squelch(self._h, float(threshold_db), float(alpha), int(bool(gate))))
@@ -135,7 +140,23 @@ class Chain(object):
         _lib.check(self._h, self._L.sdr_synchronize(self._h))
 
     # -- data path
+    def _nsamp(self, keep, dev):
+        """complex samples in a 1-D stream argument"""
+        n = int(keep.numel() if dev else keep.size)
+        if self._cu8:
+            return n // 2
+        if dev and not keep.is_complex():
+            n //= 2
+        return n
+
     def _iq_ptr(self, iq):
+        if self._cu8:
+            if _is_torch(iq) and iq.is_cuda:
+                if not iq.is_contiguous() or iq.element_size() != 1:
+                    raise ValueError("cu8 tensor must be contiguous uint8")
+                return iq.data_ptr(), 1, iq
+            a = np.ascontiguousarray(iq.cpu().numpy() if _is_torch(iq) else iq, np.uint8)
+            return a.ctypes.data, 0, a
         if _is_torch(iq):
             if not iq.is_cuda:
                 iq = iq.cpu().numpy()
@@ -149,9 +170,7 @@ class Chain(object):
     def process_iq(self, iq):
         """One streaming call (state carried): n complex64 samples."""
         ptr, dev, keep = self._iq_ptr(iq)
-        n = int(keep.numel() if dev else keep.size)
-        if dev and not keep.is_complex():
-            n //= 2
+        n = self._nsamp(keep, dev)
         _lib.check(self._h, self._L.sdr_process_iq(self._h, C.c_void_p(ptr), n, dev, C.byref(self.out)))
         return self.out
 
@@ -172,6 +191,8 @@ class Chain(object):
         ptr, dev, keep = self._iq_ptr(iq)
         ncap = int(keep.shape[0])
         n = int(keep.shape[1])
+        if self._cu8 and len(keep.shape) == 2:
+            n //= 2   # (ncap, 2n) bytes
         _lib.check(self._h, self._L.sdr_batch_process(self._h, C.c_void_p(ptr), n, n, ncap, dev, C.byref(self.out)))
         return self.out
 
@@ -213,9 +234,7 @@ class Chain(object):
             _lib.check(self._h, self._L.sdr_seek(self._h, int(abs_index), None, 0, 0))
             return
         ptr, dev, keep = self._iq_ptr(halo)
-        n = int(keep.numel() if dev else keep.size)
-        if dev and not keep.is_complex():
-            n //= 2
+        n = self._nsamp(keep, dev)
         _lib.check(self._h, self._L.sdr_seek(self._h, int(abs_index), C.c_void_p(ptr), n, dev))
 
     def segment_info(self):

@@ -8,6 +8,13 @@
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
+// rtlsdr_source's byte -> float map, (u8 - 127.4) * (1/128) per component: both ops
+// are exact in float32 (|u8 - 127.4f| < 128 needs no more than 24 bits; 2^-7 scale)
+__device__ __forceinline__ float2 cu8_to_f2(unsigned char i, unsigned char q)
+{
+    return make_float2(((float)i - 127.4f) * 0.0078125f, ((float)q - 127.4f) * 0.0078125f);
+}
+
 // exact-phase NCO: see orc nco64 in oracle/dsp_oracle.c (same op sequence)
 __device__ __forceinline__ float2 nco_eval(const float2* __restrict__ tab, unsigned long long ph)
 {
@@ -150,7 +157,20 @@ __global__ void __launch_bounds__(256) k_frontend(FrontParams P)
     const long long lo_idx = P.in0 + m_t0 * P.D - H;     // first input sample of the tile
     const int count = (T - 1) * P.D + P.ntaps;
 
+    // rtl-sdr bytes: the same two exact float ops as the oracle's cu8_to_fc32
+    const uchar2* __restrict__ xb = reinterpret_cast<const uchar2*>(P.x) + (long long)cap * P.stride;
     auto fetch = [&](long long idx) -> float2 {
+        if (P.in_fmt == SDR_IN_CU8) {
+            uchar2 u;
+            if (idx >= 0) {
+                if (idx >= P.n) return make_float2(0.f, 0.f);
+                u = xb[idx];
+            } else if (P.hist && idx >= -(long long)P.hist_len)
+                u = reinterpret_cast<const uchar2*>(P.hist)[P.hist_len + idx];
+            else
+                return make_float2(0.f, 0.f);
+            return cu8_to_f2(u.x, u.y);
+        }
         if (idx >= 0) return idx < P.n ? x[idx] : make_float2(0.f, 0.f);
         if (P.hist && idx >= -(long long)P.hist_len) return P.hist[P.hist_len + idx];
         return make_float2(0.f, 0.f);
@@ -165,7 +185,33 @@ __global__ void __launch_bounds__(256) k_frontend(FrontParams P)
         const int odd = (int)(gidx & 1);
         const long long lo_al = lo_idx - odd;
         const int pairs = (count + odd + 1) >> 1;
-        if (P.vec_ok && !P.pre_tab) {
+        if (P.in_fmt == SDR_IN_CU8 && P.vec_ok && !P.pre_tab) {
+            // 2 B/sample: the tile's bytes go by DMA into a raw area behind the float
+            // tile (16-B chunks = 8 samples, tile start moved down to a chunk boundary),
+            // then one pass converts them in place order.  Chunks that touch the
+            // capture's edges are converted from guarded loads instead.
+            unsigned char* raw = reinterpret_cast<unsigned char*>(lds + ((count + 2) & ~1));
+            const int off8 = (int)(gidx & 7);
+            const long long lo8 = lo_idx - off8;
+            const int chunks = (count + off8 + 7) >> 3;
+            for (int c0 = (threadIdx.x & ~63); c0 < chunks; c0 += T) {
+                const int c = c0 + lane_id();
+                const long long s = lo8 + 8LL * c;
+                if (c < chunks && s >= 0 && s + 8 <= P.n)
+                    __builtin_amdgcn_global_load_lds(
+                        (const __attribute__((address_space(1))) void*)(xb + s),
+                        (__attribute__((address_space(3))) void*)(raw + 16 * c0), 16, 0, 0);
+            }
+            __syncthreads();
+            for (int i = threadIdx.x; i < count; i += T) {
+                const long long s = lo8 + 8LL * ((i + off8) >> 3);
+                if (s >= 0 && s + 8 <= P.n) {
+                    const uchar2 u = reinterpret_cast<const uchar2*>(raw)[i + off8];
+                    lds[i] = cu8_to_f2(u.x, u.y);
+                } else
+                    lds[i] = fetch(lo_idx + i);
+            }
+        } else if (P.in_fmt == SDR_IN_FC32 && P.vec_ok && !P.pre_tab) {
             // Every 16-B chunk that lies inside the capture goes by DMA; only the few
             // chunks that touch the capture's edges (zero padding / streaming history)
             // are fetched by their lanes with guarded loads.  (First and last tile of a

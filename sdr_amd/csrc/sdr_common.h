@@ -40,7 +40,8 @@ struct FrontParams {
     unsigned long long pre_inc;   // !=0: rotate every INPUT sample by nco64(pre_idx0+idx) while staging (xlating with taps=[1] ahead of the FIR)
     unsigned long long pre_idx0;  // absolute index of x[0]
     const float2* pre_tab;
-    int vec_ok;             // x is 16-B aligned and stride is even: 16-B direct-to-LDS staging allowed
+    int vec_ok;             // x is 16-B aligned and stride is even (a multiple of 8 for cu8): 16-B direct-to-LDS staging allowed
+    int in_fmt;             // SDR_IN_FC32: x/hist are complex64 | SDR_IN_CU8: x/hist are (u8 I, u8 Q) pairs, converted while staging
     int D;
     int ntaps;
     int taps_complex;

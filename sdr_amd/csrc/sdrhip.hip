@@ -79,6 +79,8 @@ struct sdr_handle {
     SquelchState* d_sq_st = nullptr;
 
     sdr_handle* pre = nullptr;  // upstream channel-filter stage (sdr_set_prefilter)
+    int in_fmt = SDR_IN_FC32;   // sample format of this stage's input (sdr_set_input_format)
+    size_t ss() const { return in_fmt == SDR_IN_CU8 ? 2 : sizeof(float2); }  // bytes per input sample
     int front_mode = 0;  // 0 auto, 1 LDS/VALU kernel only, 2 MFMA kernel whenever it fits (env SDR_FRONTEND=auto|valu|mfma)
 
     // internal modes used by the FM chain (fm_host.h)
@@ -338,14 +340,19 @@ static void pick_tile(const sdr_handle* h, int& T, size_t& lds, bool& use_lds)
     const int D = h->cfg.decim, nt = h->ntaps;
     const int cands[3] = {256, 128, 64};
     use_lds = true;
+    // +2: 16-B aligned tile start; cu8 input adds the raw byte area behind the float tile
+    auto bytes = [&](int t) {
+        const size_t count = (size_t)(t - 1) * D + nt;
+        return (count + 2) * sizeof(float2) + (h->in_fmt == SDR_IN_CU8 ? ((count + 14) / 8 + 1) * 16 : 0);
+    };
     if (const char* e = getenv("SDR_TILE")) {  // tuning override: 64 | 128 | 256
         T = atoi(e);
-        lds = ((size_t)(T - 1) * D + nt + 2) * sizeof(float2);
+        lds = bytes(T);
         if ((T == 64 || T == 128 || T == 256) && lds <= 60 * 1024) return;
     }
     for (int i = 0; i < 3; ++i) {
         T = cands[i];
-        lds = ((size_t)(T - 1) * D + nt + 2) * sizeof(float2);  // +2: 16-B aligned tile start
+        lds = bytes(T);
         if (lds <= 52 * 1024) return;  // 3 two-wave workgroups per CU measured 4 % faster than 6 one-wave ones
     }
     if (lds <= 60 * 1024) return;
@@ -370,7 +377,7 @@ static size_t mfma_lds_bytes(int D, int ntaps, int nw)
 // enough flops per input sample that the LDS-walking kernel is not HBM bound.
 static bool pick_mfma(const sdr_handle* h, int& T, size_t& lds)
 {
-    if (h->front_mode == 1 || h->rt_complex) return false;
+    if (h->front_mode == 1 || h->rt_complex || h->in_fmt != SDR_IN_FC32) return false;
     const int D = h->cfg.decim, nt = h->ntaps;
     if (h->front_mode == 0 && 4.0 * nt / D < 24.0) return false;
     for (int nw = 4; nw >= 1; nw >>= 1) {
@@ -579,8 +586,32 @@ extern "C" int sdr_set_prefilter(sdr_handle* h, const float* taps, int n, int de
         return fail(h, r, "sdr_set_prefilter: " + e);
     }
     p->stream = h->stream;
+    p->in_fmt = h->in_fmt;  // the upstream stage reads the caller's samples
+    h->in_fmt = SDR_IN_FC32;
     h->pre = p;
     return SDR_OK;
+}
+
+static void reset_stream_counters(sdr_handle* h)
+{
+    h->in_count = h->out_count = 0;
+    h->keep_ctr = h->cfg.keep_n;
+    h->raw_n = 0;
+    h->last_ncap = 0;
+    h->last_nb = h->last_nout = h->last_bits_off = 0;
+}
+
+extern "C" int sdr_set_input_format(sdr_handle* h, int fmt)
+{
+    if (!h || (fmt != SDR_IN_FC32 && fmt != SDR_IN_CU8)) return fail(h, SDR_E_ARG, "sdr_set_input_format: unknown format");
+    if (h->prerotate) return fail(h, SDR_E_ARG, "sdr_set_input_format: not available on this chain");
+    (void)hipSetDevice(h->device);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    sdr_handle* t = h->pre ? h->pre : h;
+    t->in_fmt = fmt;
+    reset_stream_counters(t);
+    if (t != h) reset_stream_counters(h);
+    return reset_dec_state(h);
 }
 
 extern "C" int sdr_set_squelch(sdr_handle* h, double threshold_db, double alpha, int gate)
@@ -682,7 +713,8 @@ static int launch_front(sdr_handle* h, const float2* x, long long stride, long l
     P.nout = g.nout;
     P.in0 = g.in0;
     P.hist_len = hist_len;
-    P.vec_ok = ((((uintptr_t)x) & 15) == 0 && (stride % 2) == 0) ? 1 : 0;
+    P.in_fmt = h->in_fmt;
+    P.vec_ok = ((((uintptr_t)x) & 15) == 0 && (stride % (h->in_fmt == SDR_IN_CU8 ? 8 : 2)) == 0) ? 1 : 0;
     P.D = c.decim;
     P.ntaps = h->ntaps;
     P.taps_complex = h->rt_complex;
@@ -942,7 +974,7 @@ extern "C" int sdr_batch_process(sdr_handle* h, const void* iq, size_t n, size_t
     if (!is_dev) {
         int r = ensure_iq_staging(h, (size_t)ncap * stride);
         if (r) return r;
-        HIPCHK(h, hipMemcpyAsync(h->d_iq, iq, (size_t)((ncap - 1) * stride + n) * sizeof(float2),
+        HIPCHK(h, hipMemcpyAsync(h->d_iq, iq, (size_t)((ncap - 1) * stride + n) * h->ss(),
                                  hipMemcpyHostToDevice, h->stream));
         x = h->d_iq;
     }
@@ -975,6 +1007,19 @@ extern "C" int sdr_batch_process(sdr_handle* h, const void* iq, size_t n, size_t
     return finish_out(h, out, (unsigned long long)n * ncap, g.ne);
 }
 
+// Streaming history as the kernels see it: only the samples that exist (the zeros
+// before stream start are not representable in cu8 and are supplied by the kernels'
+// own padding); hist[valid + idx] is sample idx < 0 of the call.
+static int hist_valid(const sdr_handle* h)
+{
+    return h->in_count < (unsigned long long)h->hist_len ? (int)h->in_count : h->hist_len;
+}
+static const float2* hist_ptr(const sdr_handle* h)
+{
+    const char* b = reinterpret_cast<const char*>(h->d_hist[h->hist_sel]);
+    return reinterpret_cast<const float2*>(b + (size_t)(h->hist_len - hist_valid(h)) * h->ss());
+}
+
 static int stream_decode_step(sdr_handle* h, const CallGeom& g, const float2* x, long long n,
                               bool have_iq, sdr_out* out, unsigned long long n_in)
 {
@@ -990,7 +1035,7 @@ static int stream_decode_step(sdr_handle* h, const CallGeom& g, const float2* x,
     const long long nb_total = (off == 0) ? g.ne : total;
     int r;
     if (have_iq)
-        r = launch_front_and_back(h, x, 0, n, 1, h->d_hist[h->hist_sel], h->hist_len, g, off, nb_total, 0, 1, run);
+        r = launch_front_and_back(h, x, 0, n, 1, hist_ptr(h), hist_valid(h), g, off, nb_total, 0, 1, run);
     else {
         CallGeom g0 = g;
         g0.nout = 0;
@@ -1026,7 +1071,7 @@ extern "C" int sdr_process_iq(sdr_handle* h, const void* iq, size_t n, int is_de
     if (!is_dev && n) {
         int r = ensure_iq_staging(h, n);
         if (r) return r;
-        HIPCHK(h, hipMemcpyAsync(h->d_iq, iq, n * sizeof(float2), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->d_iq, iq, n * h->ss(), hipMemcpyHostToDevice, h->stream));
         x = h->d_iq;
     }
     const unsigned long long A = h->in_count;
@@ -1040,7 +1085,7 @@ extern "C" int sdr_process_iq(sdr_handle* h, const void* iq, size_t n, int is_de
     long long nkept = nout;  // items that reach the slicer
     if (h->squelch_on) {
         // the gate makes the item count data dependent: one 4-byte read-back per call
-        r = launch_squelch_stage(h, x, 0, (long long)n, 1, h->d_hist[h->hist_sel], h->hist_len, g, 0);
+        r = launch_squelch_stage(h, x, 0, (long long)n, 1, hist_ptr(h), hist_valid(h), g, 0);
         if (r) return r;
         int32_t cnt = 0;
         HIPCHK(h, hipMemcpyAsync(&cnt, h->d_sq_cnt, sizeof cnt, hipMemcpyDeviceToHost, h->stream));
@@ -1056,14 +1101,15 @@ extern "C" int sdr_process_iq(sdr_handle* h, const void* iq, size_t n, int is_de
     h->carry_next = -1;
     // history for the next call: last hist_len samples of (hist ++ x)
     if (n) {
-        const int H = h->hist_len;
-        float2* cur = h->d_hist[h->hist_sel];
-        float2* nxt = h->d_hist[h->hist_sel ^ 1];
-        if ((long long)n >= H)
-            HIPCHK(h, hipMemcpyAsync(nxt, x + (n - H), (size_t)H * sizeof(float2), hipMemcpyDeviceToDevice, h->stream));
+        const size_t H = (size_t)h->hist_len, ss = h->ss();
+        const char* xb = reinterpret_cast<const char*>(x);
+        char* cur = reinterpret_cast<char*>(h->d_hist[h->hist_sel]);
+        char* nxt = reinterpret_cast<char*>(h->d_hist[h->hist_sel ^ 1]);
+        if (n >= H)
+            HIPCHK(h, hipMemcpyAsync(nxt, xb + (n - H) * ss, H * ss, hipMemcpyDeviceToDevice, h->stream));
         else {
-            HIPCHK(h, hipMemcpyAsync(nxt, cur + n, (size_t)(H - n) * sizeof(float2), hipMemcpyDeviceToDevice, h->stream));
-            HIPCHK(h, hipMemcpyAsync(nxt + (H - n), x, n * sizeof(float2), hipMemcpyDeviceToDevice, h->stream));
+            HIPCHK(h, hipMemcpyAsync(nxt, cur + n * ss, (H - n) * ss, hipMemcpyDeviceToDevice, h->stream));
+            HIPCHK(h, hipMemcpyAsync(nxt + (H - n) * ss, xb, n * ss, hipMemcpyDeviceToDevice, h->stream));
         }
         h->hist_sel ^= 1;
     }
@@ -1309,10 +1355,11 @@ extern "C" int sdr_seek(sdr_handle* h, uint64_t abs_index, const void* halo, siz
     if (n_halo < need || (need && !halo))
         return fail(h, SDR_E_ARG, "sdr_seek: halo shorter than min(abs_index, sdr_history_len)");
     (void)hipSetDevice(h->device);
-    float2* cur = h->d_hist[h->hist_sel];
+    char* cur = reinterpret_cast<char*>(h->d_hist[h->hist_sel]);
+    const size_t ss = h->ss();
     HIPCHK(h, hipMemsetAsync(cur, 0, (size_t)h->hist_cap * sizeof(float2), h->stream));
     if (need)
-        HIPCHK(h, hipMemcpyAsync(cur + (H - need), (const float2*)halo + (n_halo - need), need * sizeof(float2),
+        HIPCHK(h, hipMemcpyAsync(cur + (H - need) * ss, (const char*)halo + (n_halo - need) * ss, need * ss,
                                  is_dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     const unsigned long long D = (unsigned long long)h->cfg.decim, kn = (unsigned long long)h->cfg.keep_n;
