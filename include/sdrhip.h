@@ -61,7 +61,9 @@ enum {
     SDR_DEC_TFA_GRC = 3,/* ref: TFA/analyzer2.grc:765-983 (adds the NaN guard) */
     SDR_DEC_SOMFY = 4,  /* ref: somfy/sniff.py:28-117 + somfy/decoder.py:27-58 */
     SDR_DEC_BERNER = 5, /* ref: berner/sniff.py:21-44 */
-    SDR_DEC_MUMBI = 6   /* ref: mumbi/sniff.py:26-65 */
+    SDR_DEC_MUMBI = 6,  /* ref: mumbi/sniff.py:26-65 */
+    SDR_DEC_KWMOBILE = 7, /* ref: kwmobile/decoder.py:95-135 (Nexus-type PPM, 36 bits) */
+    SDR_DEC_BALDR = 8   /* ref: baldr/decoder.py:87-142 (PPM, 37 bits, one decode per transmission) */
 };
 
 /* frame status (the reference reports these as debug strings) */
@@ -107,10 +109,11 @@ typedef struct sdr_frame {
     int32_t status;    /* SDR_FRAME_* */
     int32_t nbits;     /* raw bits the symbol rule produced */
     int32_t nbytes;    /* valid bytes in `bytes` */
-    uint8_t bytes[16]; /* packet (TS33C 10, TFA 11, somfy 7 de-obfuscated, berner 4, mumbi 5) */
+    uint8_t bytes[16]; /* packet (TS33C 10, TFA 11, somfy 7 de-obfuscated, berner 4, mumbi 5, kwmobile 5, baldr 5) */
     uint8_t raw[8];    /* somfy: the 7 on-air (obfuscated) bytes */
-    int32_t v[4];      /* TS33C: channel, rolling code, battery_ok, humidity | TFA: id, humidity, battery_ok, 0 | somfy: control, rolling code, address, clock */
-    int32_t temp_tenths; /* TS33C/TFA temperature in 0.1 C */
+    int32_t v[4];      /* TS33C: channel, rolling code, battery_ok, humidity | TFA: id, humidity, battery_ok, 0 | somfy: control, rolling code, address, clock
+                          | kwmobile: sensor_id, humidity, battery_ok, channel | baldr: sensor_id, humidity, txMode, channel */
+    int32_t temp_tenths; /* TS33C/TFA/kwmobile/baldr temperature in 0.1 C */
     int32_t pad_;
     double lim[2];     /* TS33C: pulse/gap short limit (us) | TFA: symbol_length (us), 0 */
     int64_t end_pos;   /* index (decoder-rate samples, per call) where the frame ended */

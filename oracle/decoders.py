@@ -489,6 +489,99 @@ class MumbiSniffer(object):
             self.state = 0
 
 
+# ------------------------------------------------------------------ kwmobile
+class KwmobileDecoder(object):
+    """kwmobile/decoder.py:58-135 callback rule + decode (watchdog 3 ms, :145).
+    Integer field maths as numpy 1.x promoted it (Python ints)."""
+
+    def __init__(self):
+        self.start_tick = 0
+        self.symbol_tolerance = 50
+        self.state = 0
+        self.symbols = np.empty(0, dtype=np.uint8)
+        self.frames = []
+
+    def cbf(self, level, tick):
+        tol = self.symbol_tolerance
+        if level == 1:
+            delta = (tick - self.start_tick) & 0xFFFFFFFF
+            self.start_tick = tick
+            if self.state == 0 and delta in range(4500 - 4 * tol, 4500 + 4 * tol):
+                self.state = 1
+            elif (self.state == 1) and delta in range(2500 - 2 * tol, 2500 + 2 * tol):
+                self.symbols = np.append(self.symbols, [1])
+            elif (self.state == 1) and delta in range(1500 - 2 * tol, 1500 + 2 * tol):
+                self.symbols = np.append(self.symbols, [0])
+        elif (level == 2) and (self.state > 0):
+            if self.symbols.size == 36:
+                self.frames.append(kwmobile_decode(self.symbols))
+            self.symbols = np.empty(0, dtype=np.uint8)
+            self.state = 0
+
+
+def kwmobile_decode(symbols):
+    """kwmobile/decoder.py:126-134 on 36 symbols."""
+    frame = [int(v) for v in np.packbits(np.asarray(symbols, np.uint8))]
+    return dict(frame=bytes(bytearray(frame)),
+                temperature=float(((frame[1] & 0x0f) << 8 | frame[2]) / 10.),
+                humidity=int(((frame[3] & 0x0f) << 4) + (frame[4] >> 4)),
+                channel=int((frame[1] & 0x30) >> 4),
+                battery_ok=int(frame[1] & 0x80) == 0x80,
+                sensor_id=int(frame[0]))
+
+
+# --------------------------------------------------------------------- baldr
+class BaldrDecoder(object):
+    """baldr/decoder.py:53-142 callback rule + decode (watchdog 18 ms, :152)."""
+
+    def __init__(self):
+        self.start_tick = 0
+        self.pulse_medium_gap = 2650
+        self.pulse_long_gap = 4700
+        self.pulse_verylong_gap = 9600
+        self.symbol_tolerance = 200
+        self.state = 0
+        self.symbols = np.empty(0, dtype=np.uint8)
+        self.frames = []
+
+    def cbf(self, level, tick):
+        tol = self.symbol_tolerance
+        if level == 1:
+            delta = (tick - self.start_tick) & 0xFFFFFFFF
+            self.start_tick = tick
+            if self.state == 0 and delta in range(self.pulse_verylong_gap - tol, self.pulse_verylong_gap + tol):
+                self.state = 1
+            elif (self.state == 1) and delta in range(self.pulse_long_gap - tol, self.pulse_long_gap + tol):
+                self.symbols = np.append(self.symbols, [1])
+            elif (self.state == 1) and delta in range(self.pulse_medium_gap - tol, self.pulse_medium_gap + tol):
+                self.symbols = np.append(self.symbols, [0])
+            elif (self.state == 1) and delta in range(self.pulse_verylong_gap - tol, self.pulse_verylong_gap + tol):
+                if self.symbols.size == 37:
+                    self.state = 2
+                else:
+                    self.symbols = np.empty(0, dtype=np.uint8)
+                    self.state = 0
+        elif (level == 2) and (self.state > 0):
+            if self.symbols.size == 37:
+                self.frames.append(baldr_decode(self.symbols))
+            self.symbols = np.empty(0, dtype=np.uint8)
+            self.state = 0
+
+
+def baldr_decode(symbols):
+    """baldr/decoder.py:126-141 on 37 symbols."""
+    frame = [int(v) for v in np.packbits(np.asarray(symbols, np.uint8))]
+    temp_raw = (frame[2] << 4) | (frame[3] >> 4)
+    if temp_raw > 0x7ff:
+        temp_raw -= 2 ** 12
+    return dict(frame=bytes(bytearray(frame)),
+                temperature=float(temp_raw) / 10.,
+                humidity=int(((frame[3] & 0x07) << 4) | (frame[4] >> 4)),
+                channel=int(frame[1] & 0x03),
+                txMode=int(frame[1] & 0x04),
+                sensor_id=int(((frame[0] & 0x0f) << 4) | (frame[1] >> 4)))
+
+
 def edges_to_events(bits, sample_rate, watchdog_us=None, start_level=0):
     """Turn a sliced 0/1 stream into the (level, tick) events a pigpio
     EITHER_EDGE callback with an optional watchdog would deliver: tick = sample

@@ -13,7 +13,7 @@ SDR_OK, SDR_E_ARG, SDR_E_HIP, SDR_E_CAPACITY, SDR_E_OVERFLOW, SDR_E_NODEVICE = 0
 WIN_HAMMING, WIN_HANN, WIN_BLACKMAN, WIN_RECTANGULAR, WIN_KAISER, WIN_BLACKMAN_HARRIS = range(6)
 DEMOD_NONE, DEMOD_MAG2, DEMOD_QUAD = 0, 1, 2
 IN_FC32, IN_CU8 = 0, 1
-DEC_NONE, DEC_TS33C, DEC_TFA, DEC_TFA_GRC, DEC_SOMFY, DEC_BERNER, DEC_MUMBI = range(7)
+DEC_NONE, DEC_TS33C, DEC_TFA, DEC_TFA_GRC, DEC_SOMFY, DEC_BERNER, DEC_MUMBI, DEC_KWMOBILE, DEC_BALDR = range(9)
 
 FRAME_OK = 0
 FRAME_BAD_LENGTH = 1

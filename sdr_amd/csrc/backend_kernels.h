@@ -490,6 +490,128 @@ SDR_HD inline void rule_mumbi(const EdgeCtx& e, const BackParams& P, DecState* s
     if (end_tick - prev_tick > wd) watchdog(e.nb);
 }
 
+// kwmobile/decoder.py:95-135 (Nexus-type PPM sensor; watchdog 3 ms, :145).  Only the
+// rising edges matter: delta = time between consecutive ends of gap.
+SDR_HD inline void rule_kwmobile(const EdgeCtx& e, const BackParams& P, DecState* st, int cap,
+                                 unsigned char* bits)
+{
+    const int tol = 50;
+    const long long wd = 3000;
+    long long start_tick = 0, prev_tick = 0;
+    int state = 0, nbits = 0;
+    int level = e.first_level;
+    auto watchdog = [&](long long at) {
+        if (state > 0) {
+            if (nbits == 36) {
+                sdr_frame* f = next_frame(P, st, cap, at);
+                if (f) {
+                    for (int i = 0; i < 36; ++i)
+                        if (bits[i]) f->bytes[i >> 3] |= (unsigned char)(0x80u >> (i & 7));
+                    const unsigned char* b = f->bytes;
+                    f->nbits = 36;
+                    f->nbytes = 5;
+                    f->temp_tenths = ((b[1] & 0x0f) << 8) | b[2];
+                    f->v[0] = b[0];                                   // sensor_id
+                    f->v[1] = ((b[3] & 0x0f) << 4) + (b[4] >> 4);     // humidity
+                    f->v[2] = (b[1] & 0x80) == 0x80;                  // battery_ok
+                    f->v[3] = (b[1] & 0x30) >> 4;                     // channel
+                    f->status = SDR_FRAME_OK;
+                }
+            }
+            nbits = 0;
+            state = 0;
+        }
+    };
+    auto event = [&](int lvl, long long tick) {
+        if (lvl != 1) return;
+        long long delta = tick - start_tick;
+        start_tick = tick;
+        if (state == 0 && in_range(delta, 4500 - 4 * tol, 4500 + 4 * tol))
+            state = 1;
+        else if (state == 1 && in_range(delta, 2500 - 2 * tol, 2500 + 2 * tol)) {
+            if (nbits < 512) bits[nbits++] = 1;
+        } else if (state == 1 && in_range(delta, 1500 - 2 * tol, 1500 + 2 * tol)) {
+            if (nbits < 512) bits[nbits++] = 0;
+        }
+    };
+    if (level == 1) event(1, 0);
+    for (long long k = 1; k < e.R; ++k) {
+        long long tick = tick_of(e, k);
+        if (tick - prev_tick > wd) watchdog(e.pos[k]);
+        level ^= 1;
+        event(level, tick);
+        prev_tick = tick;
+    }
+    long long end_tick = (e.nb * 1000000LL) / e.rate_hz;
+    if (end_tick - prev_tick > wd) watchdog(e.nb);
+}
+
+// baldr/decoder.py:87-142 (watchdog 18 ms, :152): one decode per transmission, of the
+// first complete 37-bit frame that follows an inter-frame gap.
+SDR_HD inline void rule_baldr(const EdgeCtx& e, const BackParams& P, DecState* st, int cap,
+                              unsigned char* bits)
+{
+    const int tol = 200;
+    const long long wd = 18000;
+    const long long medium = 2650, lng = 4700, verylong = 9600;
+    long long start_tick = 0, prev_tick = 0;
+    int state = 0, nbits = 0;
+    int level = e.first_level;
+    auto watchdog = [&](long long at) {
+        if (state > 0) {
+            if (nbits == 37) {
+                sdr_frame* f = next_frame(P, st, cap, at);
+                if (f) {
+                    for (int i = 0; i < 37; ++i)
+                        if (bits[i]) f->bytes[i >> 3] |= (unsigned char)(0x80u >> (i & 7));
+                    const unsigned char* b = f->bytes;
+                    f->nbits = 37;
+                    f->nbytes = 5;
+                    int t = ((int)b[2] << 4) | (b[3] >> 4);
+                    if (t > 0x7ff) t -= 4096;
+                    f->temp_tenths = t;
+                    f->v[0] = ((b[0] & 0x0f) << 4) | (b[1] >> 4);     // sensor_id
+                    f->v[1] = ((b[3] & 0x07) << 4) | (b[4] >> 4);     // humidity
+                    f->v[2] = b[1] & 0x04;                            // txMode
+                    f->v[3] = b[1] & 0x03;                            // channel
+                    f->status = SDR_FRAME_OK;
+                }
+            }
+            nbits = 0;
+            state = 0;
+        }
+    };
+    auto event = [&](int lvl, long long tick) {
+        if (lvl != 1) return;
+        long long delta = tick - start_tick;
+        start_tick = tick;
+        if (state == 0 && in_range(delta, verylong - tol, verylong + tol))
+            state = 1;
+        else if (state == 1 && in_range(delta, lng - tol, lng + tol)) {
+            if (nbits < 512) bits[nbits++] = 1;
+        } else if (state == 1 && in_range(delta, medium - tol, medium + tol)) {
+            if (nbits < 512) bits[nbits++] = 0;
+        } else if (state == 1 && in_range(delta, verylong - tol, verylong + tol)) {
+            if (nbits == 37)
+                state = 2;
+            else {
+                nbits = 0;
+                state = 0;
+            }
+        }
+    };
+    if (level == 1) event(1, 0);
+    for (long long k = 1; k < e.R; ++k) {
+        long long tick = tick_of(e, k);
+        if (tick - prev_tick > wd) watchdog(e.pos[k]);
+        level ^= 1;
+        event(level, tick);
+        prev_tick = tick;
+    }
+    long long end_tick = (e.nb * 1000000LL) / e.rate_hz;
+    if (end_tick - prev_tick > wd) watchdog(e.nb);
+}
+
 // ---- the stream decoder front end (TS33C/stream_decoder.py:39-110,204-217) ----
 // W(k) = k-th run width in us; `cur` = currentSymbols working array (LDS on the
 // device), `st` = a private copy of the persistent state.

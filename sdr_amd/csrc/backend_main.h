@@ -223,6 +223,10 @@ __global__ void __launch_bounds__(BK_THREADS) k_backend(BackParams P)
             rule_berner(e, P, &ls, cap, s_bits);
         else if (P.decoder == SDR_DEC_MUMBI)
             rule_mumbi(e, P, &ls, cap, s_bits);
+        else if (P.decoder == SDR_DEC_KWMOBILE)
+            rule_kwmobile(e, P, &ls, cap, s_bits);
+        else if (P.decoder == SDR_DEC_BALDR)
+            rule_baldr(e, P, &ls, cap, s_bits);
     }
     if (tid == 0) *st = ls;
 }

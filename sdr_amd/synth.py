@@ -239,6 +239,57 @@ MUMBI_CODES = {  # mumbi/transmitter.py:18-29 (34 bits = first 34 of 5 bytes)
 }
 
 
+# --------------------------------------------------------- kwmobile / baldr
+
+
+def kwmobile_bits(sensor_id, channel, battery_ok, temp_tenths, humidity):
+    """36 bits laid out as kwmobile/decoder.py:128-133 reads them (README frame
+    `80 81 26 F5 E0`: the high nibble of byte 3 is constant 0xF)."""
+    f = [sensor_id & 0xff,
+         ((1 if battery_ok else 0) << 7) | ((channel & 3) << 4) | ((temp_tenths >> 8) & 0x0f),
+         temp_tenths & 0xff,
+         0xF0 | ((humidity >> 4) & 0x0f),
+         (humidity & 0x0f) << 4]
+    return [(b >> (7 - j)) & 1 for b in f for j in range(8)][:36]
+
+
+def kwmobile_symbols(bits, repeats=12, tail_gap_us=6000.0):
+    """kwmobile/README.md:32-44: 500 us pulse + 1000 us gap = 0, + 2000 us gap = 1,
+    + 4000 us gap = end of frame; the frame is sent `repeats` times."""
+    sym = []
+    for _ in range(repeats):
+        for b in bits:
+            sym += [(1, 500.0), (0, 2000.0 if b else 1000.0)]
+        sym += [(1, 500.0), (0, 4000.0)]
+    sym += [(0, tail_gap_us)]
+    return merge_symbols(sym)
+
+
+def baldr_bits(sensor_id, channel, tx_mode, temp_tenths, humidity, lead_nibble=0x5, last_bit=0):
+    """37 bits laid out as baldr/decoder.py:128-140 reads them (12-bit two's
+    complement temperature)."""
+    t = temp_tenths & 0xfff
+    f = [((lead_nibble & 0xf) << 4) | ((sensor_id >> 4) & 0x0f),
+         ((sensor_id & 0x0f) << 4) | (4 if tx_mode else 0) | (channel & 3),
+         (t >> 4) & 0xff,
+         ((t & 0x0f) << 4) | ((humidity >> 4) & 0x07),
+         ((humidity & 0x0f) << 4) | ((last_bit & 1) << 3)]
+    return [(b >> (7 - j)) & 1 for b in f for j in range(8)][:37]
+
+
+def baldr_symbols(bits, repeats=7, tail_gap_us=25000.0):
+    """baldr/README.md:27-46: 50 us start pulse + 9000 us gap, then per frame 585 us
+    pulse + 2000 us gap = 0, + 4000 us gap = 1, + 9000 us gap between frames;
+    a last 585 us pulse ends the transmission."""
+    sym = [(1, 50.0), (0, 9000.0)]
+    for _ in range(repeats):
+        for b in bits:
+            sym += [(1, 585.0), (0, 4000.0 if b else 2000.0)]
+        sym += [(1, 585.0), (0, 9000.0)]
+    sym += [(1, 585.0), (0, tail_gap_us)]
+    return merge_symbols(sym)
+
+
 # --------------------------------------------------------------- envelopes
 
 

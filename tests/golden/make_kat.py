@@ -9,6 +9,7 @@ quoted from READMEs / doc images / array literals, with their source lines:
   TFA/docs/Decoding_Description.png 88 raw bits -> 11 bytes
   somfy/decoder.py:18-27, somfy/README.md:30-35,50-56
   mumbi/transmitter.py:18-29, berner/README.md:45
+  kwmobile/README.md:50-71          rtl_433 row + sniff.py line (Nexus PPM sensor)
 Run from the repo root in the build container (reads nothing at run time).
 """
 import json, os
@@ -39,7 +40,11 @@ kat = {
  "somfy_readme2": {"frame_hex": "a3480003405236", "payload_hex": "a3ebebe8a8facc"},
  "somfy_readme_cksum": {"frame_hex": "a6161146bd5f36", "checksum_ok": True},
  "mumbi_codes": {"a_on":[0x19,0x10,0x0F,0x09,0x00],"a_off":[0x19,0x10,0x0E,0x08,0x00],"b_on":[0x19,0x10,0x0D,0x0A,0x00],"b_off":[0x19,0x10,0x0C,0x0B,0x00],"c_on":[0x19,0x10,0x0B,0x0E,0x00],"c_off":[0x19,0x10,0x0A,0x0F,0x00],"d_on":[0x19,0x10,0x07,0x01,0x00],"d_off":[0x19,0x10,0x06,0x00,0x00],"all_on":[0x19,0x10,0x04,0x03,0x00],"all_off":[0x19,0x10,0x08,0x0D,0x00]},
- "berner_example": {"code_hex": "02eaabbf"}
+ "berner_example": {"code_hex": "02eaabbf"},
+ "kwmobile_sniff": {"frame_hex": "808126f5e0", "bits": "100000001000000100100110111101011110",
+                    "sensor_id": 128, "channel": 0, "battery_ok": True, "temperature": 29.4, "humidity": 94},
+ "kwmobile_rtl433": {"frame_hex": "808111f600", "bits": "100000001000000100010001111101100000",
+                     "sensor_id": 128, "channel": 0, "battery_ok": True, "temperature": 27.3, "humidity": 96}
 }
 out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "kat.json")
 json.dump(kat, open(out, "w"), indent=1)

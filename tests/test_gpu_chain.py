@@ -298,6 +298,10 @@ def test_rule_decoders_from_iq(kat):
     cases.append((chain.DEC_BERNER, synth.berner_symbols(0x02EAABBF), 3000.0, odec.BernerSniffer, None))
     cases.append((chain.DEC_MUMBI, synth.mumbi_symbols(bytes(kat["mumbi_codes"]["c_on"]), repeats=4), 9000.0,
                   odec.MumbiSniffer, 8000))
+    kw = [int(ch) for ch in kat["kwmobile_sniff"]["bits"]]
+    cases.append((chain.DEC_KWMOBILE, synth.kwmobile_symbols(kw, repeats=4), 4000.0, odec.KwmobileDecoder, 3000))
+    cases.append((chain.DEC_BALDR, synth.baldr_symbols(synth.baldr_bits(0x3C, 1, 0, 217, 48)), 3000.0,
+                  odec.BaldrDecoder, 18000))
     for decoder, sym, lead, cls, wd in cases:
         env = synth.envelope(sym, fs, lead_in_us=lead)
         iq = synth.ook_iq(env, fs, rng=rng)
@@ -316,8 +320,15 @@ def test_rule_decoders_from_iq(kat):
             if decoder == chain.DEC_SOMFY:
                 assert b.packet() == a["frame"] and bytes(bytearray(b.raw[:7])) == a["raw"] == fr
                 assert b.status == 0 and b.v[1] == 0x1234 and b.v[2] == 0xABCDEF
+            elif decoder in (chain.DEC_KWMOBILE, chain.DEC_BALDR):
+                assert b.packet() == a["frame"] and b.temp_tenths / 10. == a["temperature"]
+                assert (b.v[0], b.v[1], b.v[3]) == (a["sensor_id"], a["humidity"], a["channel"])
             else:
                 assert b.packet() == a
+        if decoder == chain.DEC_KWMOBILE:
+            assert [f.packet().hex() for f in frames] == [kat["kwmobile_sniff"]["frame_hex"]] * 3
+        if decoder == chain.DEC_BALDR:
+            assert len(frames) == 1 and frames[0].temp_tenths == 217 and frames[0].v[1] == 48
 
 
 def test_edge_cases():

@@ -275,6 +275,30 @@ def test_rule_decoders_host_vs_oracle(L, seed, kat):
     g.work(env.astype(np.int8))
     assert [f.packet() for f in g.frames] == of and len(of) == 4
     g.close()
+    # kwmobile (Nexus PPM)
+    bits = synth.kwmobile_bits(int(rng.integers(0, 256)), int(rng.integers(0, 3)), bool(rng.integers(0, 2)),
+                               int(rng.integers(0, 600)), int(rng.integers(0, 100)))
+    env = _jitter_env(rng, synth.envelope(synth.kwmobile_symbols(bits, repeats=5), rate, lead_in_us=4000.0))
+    of = _events_decode(dec.KwmobileDecoder, env, rate, 3000)
+    g = HostDec(L, _lib.DEC_KWMOBILE, rate)
+    g.work(env.astype(np.int8))
+    assert len(of) == 4 and [f.packet() for f in g.frames] == [f["frame"] for f in of]
+    for a, b in zip(of, g.frames):
+        assert (b.v[0], b.v[1], bool(b.v[2]), b.v[3]) == (a["sensor_id"], a["humidity"], a["battery_ok"], a["channel"])
+        assert b.temp_tenths / 10. == a["temperature"] and b.nbits == 36
+    g.close()
+    # baldr
+    bits = synth.baldr_bits(int(rng.integers(0, 256)), int(rng.integers(0, 4)), int(rng.integers(0, 2)),
+                            int(rng.integers(-400, 600)), int(rng.integers(0, 100)))
+    env = _jitter_env(rng, synth.envelope(synth.baldr_symbols(bits), rate, lead_in_us=3000.0))
+    of = _events_decode(dec.BaldrDecoder, env, rate, 18000)
+    g = HostDec(L, _lib.DEC_BALDR, rate)
+    g.work(env.astype(np.int8))
+    assert len(of) == 1 and [f.packet() for f in g.frames] == [f["frame"] for f in of]
+    for a, b in zip(of, g.frames):
+        assert (b.v[0], b.v[1], b.v[2], b.v[3]) == (a["sensor_id"], a["humidity"], a["txMode"], a["channel"])
+        assert b.temp_tenths / 10. == a["temperature"] and b.nbits == 37
+    g.close()
 
 
 def _jitter_env(rng, env):
