@@ -71,6 +71,10 @@ def lib():
         L.orc_ook_chain.argtypes = [_f32p, C.c_int64, _f32p, C.c_int, C.c_int, C.c_int, C.c_uint64,
                                     C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_int, _i8p,
                                     C.c_void_p]
+        L.orc_pfb_twiddles.restype = None
+        L.orc_pfb_twiddles.argtypes = [C.c_int, _f32p]
+        L.orc_pfb_channelize.restype = C.c_int
+        L.orc_pfb_channelize.argtypes = [_f32p, C.c_int64, _f32p, C.c_int, C.c_int, _f32p, C.c_int64, _f32p]
         _LIB = L
     return _LIB
 
@@ -261,6 +265,22 @@ def resample(x, taps, L, M, hist=None):
     y = np.zeros(xf.size * L // M + 2, np.float32)
     k = lib().orc_resample_ccc(buf.ctypes.data + 4 * H, xf.size, taps, taps.size, L, M, y, 0)
     return y[:k].copy()
+
+
+def pfb_channelize(x, taps, M=64):
+    """Critically sampled polyphase channelizer from stream start ->
+    complex64 [M, len(x)//M]; row c = the output of
+    freq_xlating_fir(x, taps, c*fs/M, fs, D=M) (see orc_pfb_channelize)."""
+    xf = _c2f(x)
+    n = xf.size // 2
+    taps = np.ascontiguousarray(taps, np.float32)
+    tw = np.zeros(2 * M, np.float32)
+    lib().orc_pfb_twiddles(M, tw)
+    nout = n // M
+    y = np.zeros(2 * M * max(nout, 1), np.float32)
+    rc = lib().orc_pfb_channelize(xf, n, taps, taps.size, M, tw, nout, y)
+    assert rc == 0
+    return y[:2 * M * nout].view(np.complex64).reshape(M, nout)
 
 
 def cu8_to_fc32(u8):

@@ -1,0 +1,207 @@
+// Polyphase channelizer, 64 sub-bands, critically sampled (BASELINE.json
+// configs[4]): y_c[m] = sum_k taps[k] e^{+j 2 pi c k/64} x[64 m - k], i.e. what a
+// bank of 64 freq_xlating_fir_filter_ccc(decim 64, taps, c*fs/64) blocks yields
+// [GR-ext], computed as 64 polyphase branch sums + a 64-point DFT, with mag^2 /
+// gain / threshold_ff / slicer / keep_one_in_n fused behind it.  HBM-bound: 8 B
+// read per input sample, 1/keep_n B written (all 64 channels together produce
+// one output per input sample).  No MFMA: the DFT is 6 butterfly stages across
+// the lanes of a wavefront, not a dense contraction.
+//
+// Numeric contract = oracle/dsp_oracle.c orc_pfb_channelize, op for op.
+//
+// Work split: a 256-thread workgroup owns 64 consecutive output times of one
+// capture; its (P+63)*64 input samples are staged once in LDS by 16-B DMA.
+// Wave w owns times 16w..16w+15.  Phase 1: lane = branch p; the lane keeps 16
+// complex accumulators and walks the 15+P sample blocks of its column once
+// (conflict-free ds_read_b64, every sample reused for up to P outputs).
+// Phase 2: the DFT over p runs across lanes (radix-2 DIF, partner = lane ^ 2^s by
+// DPP/bpermute); lane l ends up holding channel bitrev6(l).  Phase 3: lane =
+// channel; hysteresis over its 16 outputs in registers, carry across the four
+// waves through LDS, one TileSum per (channel, workgroup) for k_backend.
+#pragma once
+#include "sdr_common.h"
+#include "frontend_kernels.h"
+
+#define PFB_M 64
+#define PFB_TM 16    // output times per wave
+#define PFB_NW 4     // waves per workgroup
+#define PFB_TILE (PFB_TM * PFB_NW)
+
+struct PfbParams {
+    const float2* x;        // capture 0, sample 0
+    long long stride;       // samples between captures
+    long long n;            // samples per capture
+    long long nout;         // outputs per channel (n / 64)
+    int vec_ok;
+    const float* taps;      // prototype taps in natural order, zero-padded to P*64
+    const float2* tw;       // 64 twiddles e^{+j 2 pi k/64}
+    int demod;              // SDR_DEMOD_NONE | SDR_DEMOD_MAG2
+    float gain, lo, hi;
+    int keep_n;
+    long long keep_c0;
+    int8_t* bits;           // row = capture*64 + channel
+    long long bits_stride;
+    float* tap;
+    long long tap_stride;
+    TileSum* tsum;
+    int tiles_per_row;
+};
+
+template <int P>
+__global__ void __launch_bounds__(256) k_pfb(PfbParams Q)
+{
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    float2* lds = reinterpret_cast<float2*>(smem_raw);
+    __shared__ int sh_first[PFB_NW][PFB_M];   // first event of the wave's 16 outputs (0..15) or -1
+    __shared__ int sh_last[PFB_NW][PFB_M];
+
+    const int tile = blockIdx.x, cap = blockIdx.y;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long long m0 = (long long)tile * PFB_TILE;
+    const float2* __restrict__ x = Q.x + (long long)cap * Q.stride;
+    const long long lo_idx = (m0 - (P - 1)) * PFB_M - (PFB_M - 1);
+    constexpr int count = (P + PFB_TILE - 1) * PFB_M;
+
+    auto fetch = [&](long long idx) -> float2 {
+        return (idx >= 0 && idx < Q.n) ? x[idx] : make_float2(0.f, 0.f);
+    };
+
+    // ---- stage the tile (same scheme as k_frontend) -------------------------------
+    int lsh = 0;
+    if (Q.vec_ok) {
+        const long long gidx = (long long)cap * Q.stride + lo_idx;
+        const int odd = (int)(gidx & 1);
+        const long long lo_al = lo_idx - odd;
+        const int pairs = (count + odd + 1) >> 1;
+        lsh = odd;
+        for (int p0 = (threadIdx.x & ~63); p0 < pairs; p0 += 256) {
+            const int p = p0 + lane;
+            if (p < pairs) {
+                const long long s = lo_al + 2LL * p;
+                if (s >= 0 && s + 2 <= Q.n)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(x + s),
+                                                     (__attribute__((address_space(3))) void*)(lds + 2 * p0), 16, 0, 0);
+                else {
+                    lds[2 * p] = fetch(s);
+                    lds[2 * p + 1] = fetch(s + 1);
+                }
+            }
+        }
+    } else {
+        for (int i = threadIdx.x; i < count; i += 256) lds[i] = fetch(lo_idx + i);
+    }
+
+    // branch taps of this lane, twiddles of this lane for the six stages
+    float hq[P];
+#pragma unroll
+    for (int q = 0; q < P; ++q) hq[q] = Q.taps[lane + PFB_M * q];
+    float2 twl[6];
+#pragma unroll
+    for (int s = 0; s < 6; ++s) twl[s] = Q.tw[(lane & ((1 << s) - 1)) << (5 - s)];
+    __syncthreads();
+
+    // ---- phase 1: polyphase branch sums, lane = p ------------------------------------
+    float ar[PFB_TM], ai[PFB_TM];
+#pragma unroll
+    for (int i = 0; i < PFB_TM; ++i) ar[i] = ai[i] = 0.f;
+    const float2* col = lds + lsh + (long long)(PFB_TM * w) * PFB_M + (PFB_M - 1) - lane;
+#pragma unroll
+    for (int bb = 0; bb < PFB_TM + P - 1; ++bb) {
+        const float2 s = col[bb * PFB_M];
+#pragma unroll
+        for (int q = 0; q < P; ++q) {
+            const int i = bb - (P - 1) + q;   // compile-time after unrolling
+            if (i >= 0 && i < PFB_TM) {
+                ar[i] = __builtin_fmaf(hq[q], s.x, ar[i]);
+                ai[i] = __builtin_fmaf(hq[q], s.y, ai[i]);
+            }
+        }
+    }
+
+    // ---- phase 2: 64-point DFT across the lanes ---------------------------------------
+#pragma unroll
+    for (int i = 0; i < PFB_TM; ++i) {
+        float vr = ar[i], vi = ai[i];
+#pragma unroll
+        for (int s = 5; s >= 0; --s) {
+            const int half = 1 << s;
+            const float pr = __shfl_xor(vr, half), pi = __shfl_xor(vi, half);
+            const float sr = vr + pr, si = vi + pi;
+            const float dr = pr - vr, di = pi - vi;
+            const float ur = __builtin_fmaf(dr, twl[s].x, -(di * twl[s].y));
+            const float ui = __builtin_fmaf(dr, twl[s].y, di * twl[s].x);
+            const bool upper = (lane & half) != 0;
+            vr = upper ? ur : sr;
+            vi = upper ? ui : si;
+        }
+        ar[i] = vr;
+        ai[i] = vi;
+    }
+
+    // ---- phase 3: lane = channel bitrev6(lane) -------------------------------------------
+    const int ch = (int)(__brev((unsigned)lane) >> 26);
+    const long long row = (long long)cap * PFB_M + ch;
+    const long long o_w = m0 + PFB_TM * w;   // first output index of this wave
+    if (Q.demod == SDR_DEMOD_NONE) {
+        if (Q.tap) {
+            float2* dst = reinterpret_cast<float2*>(Q.tap + row * Q.tap_stride);
+#pragma unroll
+            for (int i = 0; i < PFB_TM; ++i)
+                if (o_w + i < Q.nout) dst[o_w + i] = make_float2(ar[i], ai[i]);
+        }
+        return;
+    }
+    unsigned states = 0;   // bit i = threshold_ff output at time i, carry-in 0
+    int first = -1, st = 0;
+#pragma unroll
+    for (int i = 0; i < PFB_TM; ++i) {
+        float v = Q.gain * __builtin_fmaf(ar[i], ar[i], ai[i] * ai[i]);
+        ar[i] = v;
+        const bool valid = o_w + i < Q.nout;
+        const int evt = valid ? (v > Q.hi ? 1 : (v < Q.lo ? 2 : 0)) : 0;
+        if (evt) {
+            if (first < 0) first = i;
+            st = evt == 1;
+        }
+        states |= (unsigned)st << i;
+    }
+    if (Q.tap) {
+        float* dst = Q.tap + row * Q.tap_stride;
+#pragma unroll
+        for (int i = 0; i < PFB_TM; ++i)
+            if (o_w + i < Q.nout) dst[o_w + i] = ar[i];
+    }
+    sh_first[w][lane] = first;
+    sh_last[w][lane] = st;
+    __syncthreads();
+    int carry = 0;   // state left by the earlier waves of this workgroup (tile carry-in taken as 0)
+    for (int v = 0; v < w; ++v)
+        if (sh_first[v][lane] >= 0) carry = sh_last[v][lane];
+    if (carry) states |= (first < 0) ? 0xffffu : ((1u << first) - 1u);
+    if (w == 0) {
+        int tf = -1, tl = 0;
+        for (int v = 0; v < PFB_NW; ++v)
+            if (sh_first[v][lane] >= 0) {
+                if (tf < 0) tf = PFB_TM * v + sh_first[v][lane];
+                tl = sh_last[v][lane];
+            }
+        TileSum t;
+        t.first_evt = tf < 0 ? -1 : (int32_t)(m0 + tf);
+        t.last_state = tl;
+        Q.tsum[row * Q.tiles_per_row + tile] = t;
+    }
+    int8_t* brow = Q.bits + row * Q.bits_stride;
+#pragma unroll
+    for (int i = 0; i < PFB_TM; ++i) {
+        const long long o = o_w + i;
+        if (o < Q.nout && o >= Q.keep_c0) {
+            const long long r = o - Q.keep_c0;
+            if (Q.keep_n == 1)
+                brow[r] = (int8_t)((states >> i) & 1u);
+            else {
+                const unsigned qq = (unsigned)r / (unsigned)Q.keep_n;   // r < 2^31: nout is bounded by the int32 TileSum index
+                if ((unsigned)r == qq * (unsigned)Q.keep_n) brow[qq] = (int8_t)((states >> i) & 1u);
+            }
+        }
+    }
+}
