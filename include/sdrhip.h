@@ -275,6 +275,24 @@ SDR_API int sdr_segment_info_get(sdr_handle* h, sdr_segment_info* info);
  * buffer on the handle's stream, ready for a collective; *n = bytes written. */
 SDR_API int sdr_export_bits(sdr_handle* h, void* bits_dev, size_t cap_bytes, size_t* n);
 
+/* ---- 64-channel polyphase channelizer (BASELINE.json configs[4]) ----------------
+ * The reference has no channelizer block; what this stands for is a bank of 64
+ * freq_xlating_fir_filter_ccc(decim 64, taps, center_freq c*fs/64) blocks (the
+ * block of FM-Radio/FM-Radio.grc:615-671, TFA/analyzer2.grc:1016-1072), each
+ * followed by the OOK tail of TS33C/live_decoder.grc:3292-3377 (mag^2 ->
+ * multiply_const -> threshold_ff -> slicer -> keep_one_in_n -> decoder).
+ * cfg as for sdr_create (decim and center_freq are ignored: decimation = 64;
+ * demod NONE or MAG2; keep_n / decoder_rate refer to the fs/64 channel streams).
+ * The handle is used like a batch chain: sdr_set_taps (prototype low-pass, real,
+ * <= 1024 taps), sdr_batch_process (whole captures from stream start),
+ * sdr_fetch_*: row r = capture*64 + channel (channel c is centred at c*fs/64,
+ * c >= 32 are the negative frequencies); sdr_frame.capture holds that row. */
+SDR_API int sdr_pfb_create(const sdr_chain_cfg* cfg, int channels, sdr_handle** out);
+/* Decode the sliced bytes of the last sdr_batch_process again with another
+ * decoder (SDR_DEC_*, decoder_rate 0 = unchanged): "all sensor decoders run
+ * concurrently per channel".  Replaces the frame table. */
+SDR_API int sdr_redecode(sdr_handle* h, int decoder, double decoder_rate);
+
 /* ---- FM-Radio chain (BASELINE.json configs[1]) --------------------------------
  * ref: FM-Radio/FM-Radio.grc:2903-2964 wiring: freq_xlating_fir_filter_ccc
  * (taps 1, center_freq -shift) -> rational_resampler_ccc 1/int(samp_rate/500e3)

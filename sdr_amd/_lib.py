@@ -149,7 +149,7 @@ EXPORTS = [
     "sdr_preamble_last_error", "sdr_set_prefilter",
     "sdr_fm_create", "sdr_fm_destroy", "sdr_fm_set_stream", "sdr_fm_process", "sdr_fm_fetch",
     "sdr_fm_last_error",
-    "sdr_set_input_format", "sdr_history_len", "sdr_seek", "sdr_segment_info_get", "sdr_export_bits",
+    "sdr_pfb_create", "sdr_redecode", "sdr_set_input_format", "sdr_history_len", "sdr_seek", "sdr_segment_info_get", "sdr_export_bits",
 ]
 
 _lib = None
@@ -241,6 +241,10 @@ def load():
     L.sdr_profile_read.argtypes = [H, fp, fp, C.c_int, C.POINTER(C.c_int)]
     L.sdr_export_frames.restype = C.c_int
     L.sdr_export_frames.argtypes = [H, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    L.sdr_pfb_create.restype = C.c_int
+    L.sdr_pfb_create.argtypes = [C.POINTER(ChainCfg), C.c_int, C.POINTER(H)]
+    L.sdr_redecode.restype = C.c_int
+    L.sdr_redecode.argtypes = [H, C.c_int, C.c_double]
     L.sdr_set_input_format.restype = C.c_int
     L.sdr_set_input_format.argtypes = [H, C.c_int]
     L.sdr_history_len.restype = C.c_int

@@ -44,14 +44,16 @@ class Chain(object):
     def __init__(self, sample_rate, decim=1, center_freq=0.0, taps=None, demod=DEMOD_MAG2, demod_gain=1.0,
                  thr=(0.05, 0.15), thr_init=0, keep_n=1, decoder=DEC_NONE, decoder_rate=0.0, post_taps=None,
                  tap_demod=False, max_batch=1, max_frames=16, max_samples=1 << 20, squelch=None,
-                 pre_taps=None, pre_decim=1, input_format="fc32"):
+                 pre_taps=None, pre_decim=1, input_format="fc32", channels=0):
         """squelch=(threshold_db, alpha[, gate=True]): analog_pwr_squelch_cc between the channel
         filter and the demodulator (TFA/decoder.grc:391-446).
         pre_taps/pre_decim: an upstream fir_filter_ccf in front of this chain's own filter
         (mumbi/FS300.grc: low_pass_filter -> rational_resampler 1/10); sample_rate and
         max_samples are then those of the upstream input.
         input_format: "fc32" (complex64) or "cu8" (rtl-sdr bytes, uint8 I/Q pairs converted as
-        rtlsdr_source does; arrays of shape (..., n, 2) or (..., 2n) uint8)."""
+        rtlsdr_source does; arrays of shape (..., n, 2) or (..., 2n) uint8).
+        channels=64: polyphase channelizer handle (sdr_pfb_create): `taps` is the prototype
+        low-pass, decimation is 64, batch rows come back as capture*64 + channel."""
         self._L = _lib.load()
         self._cu8 = {"fc32": False, "cu8": True}[input_format]
         self._h = C.c_void_p()
@@ -74,7 +76,11 @@ class Chain(object):
         cfg.max_frames = int(max_frames)
         cfg.max_samples = int(max_samples)
         self.cfg = cfg
-        rc = self._L.sdr_create(C.byref(cfg), C.byref(self._h))
+        self.channels = int(channels)
+        if self.channels:
+            rc = self._L.sdr_pfb_create(C.byref(cfg), self.channels, C.byref(self._h))
+        else:
+            rc = self._L.sdr_create(C.byref(cfg), C.byref(self._h))
         if rc != 0:
             self._h = C.c_void_p()
             _lib.check(None, rc)
@@ -248,6 +254,10 @@ class Chain(object):
         _lib.check(self._h, self._L.sdr_export_bits(self._h, C.c_void_p(bits_tensor.data_ptr()),
                                                     bits_tensor.numel() * bits_tensor.element_size(), C.byref(n)))
         return n.value
+
+    def redecode(self, decoder, decoder_rate=0.0):
+        """Run another decoder over the last batch's sliced bytes; then fetch_frames()."""
+        _lib.check(self._h, self._L.sdr_redecode(self._h, int(decoder), float(decoder_rate)))
 
     def decoder_state(self):
         st = (C.c_int32 * 4)()

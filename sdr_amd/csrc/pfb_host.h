@@ -1,0 +1,167 @@
+// Host side of the 64-channel polyphase channelizer (sdr_pfb_create): a normal
+// chain handle whose batch rows are (capture, channel) pairs and whose front end
+// is k_pfb.  Everything behind the sliced bytes (k_backend, fetches, frame export)
+// is shared with the plain chain.
+#pragma once
+
+static int pfb_upload_taps(sdr_handle* h)
+{
+    if (h->proto_complex) return fail(h, SDR_E_ARG, "channelizer: the prototype filter must have real taps");
+    const int M = h->pfb_M, n = h->ntaps;
+    int P = 0;
+    for (int cand : {4, 8, 16})
+        if (n <= cand * M) {
+            P = cand;
+            break;
+        }
+    if (!P) return fail(h, SDR_E_ARG, "channelizer: at most 16 taps per branch (1024 taps)");
+    std::vector<float> t((size_t)P * M, 0.0f);
+    for (int k = 0; k < n; ++k) t[k] = h->proto_taps[k];
+    if (h->d_pfb_taps) (void)hipFree(h->d_pfb_taps);
+    h->d_pfb_taps = nullptr;
+    HIPCHK(h, dev_alloc((void**)&h->d_pfb_taps, t.size() * sizeof(float)));
+    HIPCHK(h, hipMemcpy(h->d_pfb_taps, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice));
+    h->pfb_P = P;
+    return SDR_OK;
+}
+
+extern "C" int sdr_pfb_create(const sdr_chain_cfg* cfg, int channels, sdr_handle** out)
+{
+    if (!cfg || !out) return fail(nullptr, SDR_E_ARG, "sdr_pfb_create: null argument");
+    *out = nullptr;
+    if (channels != PFB_M) return fail(nullptr, SDR_E_ARG, "sdr_pfb_create: 64 channels (one per wavefront lane) is the supported size");
+    if (cfg->demod == SDR_DEMOD_QUAD || cfg->post_ntaps > 0 || cfg->center_freq != 0.0)
+        return fail(nullptr, SDR_E_ARG, "sdr_pfb_create: demod NONE or MAG2, no post filter, no centre frequency");
+    if (cfg->max_batch < 1 || cfg->max_batch > (1 << 20) / PFB_M)
+        return fail(nullptr, SDR_E_ARG, "sdr_pfb_create: bad max_batch");
+    sdr_chain_cfg c2 = *cfg;
+    c2.decim = PFB_M;
+    c2.max_batch = cfg->max_batch * PFB_M;
+    sdr_handle* h = nullptr;
+    int r = sdr_create(&c2, &h);
+    if (r) return r;
+    h->pfb_M = PFB_M;
+    auto body = [&]() -> int {
+        std::vector<float2> tw(PFB_M);
+        for (int k = 0; k < PFB_M; ++k) {
+            tw[k].x = (float)cos(2.0 * M_PI * k / PFB_M);
+            tw[k].y = (float)sin(2.0 * M_PI * k / PFB_M);
+        }
+        HIPCHK(h, dev_alloc((void**)&h->d_pfb_tw, tw.size() * sizeof(float2)));
+        HIPCHK(h, hipMemcpy(h->d_pfb_tw, tw.data(), tw.size() * sizeof(float2), hipMemcpyHostToDevice));
+        return pfb_upload_taps(h);
+    };
+    r = body();
+    if (r) {
+        g_err = h->err;
+        sdr_destroy(h);
+        return r;
+    }
+    *out = h;
+    return SDR_OK;
+}
+
+static int pfb_batch(sdr_handle* h, const void* iq, size_t n, size_t stride, int ncap, int is_dev, sdr_out* out)
+{
+    const sdr_chain_cfg& c = h->cfg;
+    const int M = h->pfb_M;
+    if (ncap * M > c.max_batch || n > c.max_samples)
+        return fail(h, SDR_E_CAPACITY, "sdr_batch_process: batch larger than the channelizer was created for");
+    if (stride < n) return fail(h, SDR_E_ARG, "sdr_batch_process: stride < n_per_capture");
+    if (h->in_fmt != SDR_IN_FC32) return fail(h, SDR_E_ARG, "channelizer: complex64 input only");
+    (void)hipSetDevice(h->device);
+    const float2* x = (const float2*)iq;
+    if (!is_dev) {
+        int r = ensure_iq_staging(h, (size_t)ncap * stride);
+        if (r) return r;
+        HIPCHK(h, hipMemcpyAsync(h->d_iq, iq, (size_t)((ncap - 1) * stride + n) * sizeof(float2), hipMemcpyHostToDevice,
+                                 h->stream));
+        x = h->d_iq;
+    }
+    CallGeom g;
+    memset(&g, 0, sizeof g);
+    g.nout = (long long)(n / M);
+    g.keep_c0 = c.keep_n - 1;
+    g.ne = g.nout > g.keep_c0 ? (g.nout - g.keep_c0 + c.keep_n - 1) / c.keep_n : 0;
+    g.T = 256;
+    g.tile_out = PFB_TILE;
+    g.tiles = (int)((g.nout + PFB_TILE - 1) / PFB_TILE);
+    g.use_lds = true;
+    if (g.tiles > h->tsum_stride) return fail(h, SDR_E_CAPACITY, "tile table too small");
+    if (g.nout >= 0x7fffffffLL) return fail(h, SDR_E_CAPACITY, "capture too long for the channelizer");
+    if (c.demod == SDR_DEMOD_NONE && !h->d_tap)
+        return fail(h, SDR_E_ARG, "demod NONE needs cfg.tap_demod (complex output buffer)");
+    if (h->profile) HIPCHK(h, hipEventRecord(h->pev[3 * (h->pcount % SDR_PROF_RING)], h->stream));
+    if (g.nout > 0) {
+        PfbParams Q;
+        memset(&Q, 0, sizeof Q);
+        Q.x = x;
+        Q.stride = (long long)stride;
+        Q.n = (long long)n;
+        Q.nout = g.nout;
+        Q.vec_ok = ((((uintptr_t)x) & 15) == 0 && (stride % 2) == 0) ? 1 : 0;
+        Q.taps = h->d_pfb_taps;
+        Q.tw = h->d_pfb_tw;
+        Q.demod = c.demod;
+        Q.gain = c.demod_gain;
+        Q.lo = c.thr_lo;
+        Q.hi = c.thr_hi;
+        Q.keep_n = c.keep_n;
+        Q.keep_c0 = g.keep_c0;
+        Q.bits = h->d_bits;
+        Q.bits_stride = h->bits_stride;
+        Q.tap = (c.tap_demod || c.demod == SDR_DEMOD_NONE) ? h->d_tap : nullptr;
+        Q.tap_stride = h->tap_stride;
+        Q.tsum = h->d_tsum;
+        Q.tiles_per_row = g.tiles;
+        const size_t lds = ((size_t)(h->pfb_P + PFB_TILE - 1) * PFB_M + 2) * sizeof(float2);
+        dim3 grid(g.tiles, ncap), block(256);
+        switch (h->pfb_P) {
+        case 4: hipLaunchKernelGGL(k_pfb<4>, grid, block, lds, h->stream, Q); break;
+        case 8: hipLaunchKernelGGL(k_pfb<8>, grid, block, lds, h->stream, Q); break;
+        default: hipLaunchKernelGGL(k_pfb<16>, grid, block, lds, h->stream, Q); break;
+        }
+        HIPCHK(h, hipGetLastError());
+    }
+    int run = 1;
+    if (is_stream_decoder(c.decoder))
+        run = ((double)g.ne * 1e6 / h->dec_rate > decoder_reset_limit(c.decoder)) ? 1 : 0;
+    int r = launch_back(h, ncap * M, g, 0, g.ne, 1, 0, run);
+    if (r) return r;
+    h->last_ncap = ncap * M;
+    h->last_nb = g.ne;
+    h->last_nout = g.nout;
+    h->last_bits_off = 0;
+    h->last_keep_c0 = g.keep_c0;
+    h->last_out0 = 0;
+    return finish_out(h, out, (unsigned long long)n * ncap, g.ne);
+}
+
+// Run another decoder over the sliced bytes of the last batch (every row decoded
+// from a fresh decoder object, as in sdr_batch_process); the frame table is replaced.
+extern "C" int sdr_redecode(sdr_handle* h, int decoder, double decoder_rate)
+{
+    if (!h || decoder <= SDR_DEC_NONE || decoder > SDR_DEC_BALDR) return fail(h, SDR_E_ARG, "sdr_redecode: bad decoder");
+    if (h->cfg.demod == SDR_DEMOD_NONE || h->skip_slice) return fail(h, SDR_E_ARG, "sdr_redecode: the chain has no sliced stream");
+    if (h->last_ncap < 1) return fail(h, SDR_E_ARG, "sdr_redecode: no batch processed yet");
+    if (h->last_bits_off != 0 || h->raw_n != 0) return fail(h, SDR_E_ARG, "sdr_redecode: only after sdr_batch_process");
+    (void)hipSetDevice(h->device);
+    const int keep_dec = h->cfg.decoder;
+    const double keep_rate = h->dec_rate;
+    h->cfg.decoder = decoder;
+    if (decoder_rate > 0) h->dec_rate = decoder_rate;
+    CallGeom g;
+    memset(&g, 0, sizeof g);
+    g.ne = h->last_nb;
+    g.T = 256;
+    g.tile_out = 256;
+    int run = 1;
+    if (is_stream_decoder(decoder))
+        run = ((double)g.ne * 1e6 / h->dec_rate > decoder_reset_limit(decoder)) ? 1 : 0;
+    if (h->profile) HIPCHK(h, hipEventRecord(h->pev[3 * (h->pcount % SDR_PROF_RING)], h->stream));
+    // bits are final (tsum == nullptr): phase 0 is skipped, thr_state untouched
+    int r = launch_back(h, h->last_ncap, g, 0, g.ne, 1, 0, run);
+    h->cfg.decoder = keep_dec;
+    h->dec_rate = keep_rate;
+    return r;
+}

@@ -16,6 +16,7 @@
 #include "backend_main.h"
 #include "fm_kernels.h"
 #include "squelch_kernels.h"
+#include "pfb_kernels.h"
 
 #ifndef M_PI
 #define M_PI 3.14159265358979323846
@@ -79,6 +80,9 @@ struct sdr_handle {
     SquelchState* d_sq_st = nullptr;
 
     sdr_handle* pre = nullptr;  // upstream channel-filter stage (sdr_set_prefilter)
+    int pfb_M = 0, pfb_P = 0;   // !=0: channelizer handle (sdr_pfb_create): rows = (capture, channel), front end = k_pfb
+    float* d_pfb_taps = nullptr;
+    float2* d_pfb_tw = nullptr;
     int in_fmt = SDR_IN_FC32;   // sample format of this stage's input (sdr_set_input_format)
     size_t ss() const { return in_fmt == SDR_IN_CU8 ? 2 : sizeof(float2); }  // bytes per input sample
     int front_mode = 0;  // 0 auto, 1 LDS/VALU kernel only, 2 MFMA kernel whenever it fits (env SDR_FRONTEND=auto|valu|mfma)
@@ -391,6 +395,8 @@ static bool pick_mfma(const sdr_handle* h, int& T, size_t& lds)
     return false;
 }
 
+static int pfb_upload_taps(sdr_handle* h);
+
 // ------------------------------------------------------------------ create
 extern "C" int sdr_version(void) { return 101; }
 
@@ -424,7 +430,7 @@ extern "C" int sdr_destroy(sdr_handle* h)
     void* ptrs[] = {h->d_rtaps, h->d_post_rtaps, h->d_nco_tab, h->d_atan_tab, h->d_pow, h->d_log2, h->d_iq,
                     h->d_hist[0], h->d_hist[1], h->d_bits, h->d_tap, h->d_tap2, h->d_tsum, h->d_runs,
                     h->d_cur, h->d_st, h->d_frames, h->d_sq_y, h->d_sq_z, h->d_sq_cnt, h->d_sq_st,
-                    h->d_post_hist[0], h->d_post_hist[1], h->d_pack};
+                    h->d_post_hist[0], h->d_post_hist[1], h->d_pack, h->d_pfb_taps, h->d_pfb_tw};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (hipEvent_t e : h->pev) (void)hipEventDestroy(e);
@@ -535,6 +541,7 @@ extern "C" int sdr_set_taps(sdr_handle* h, const float* taps, int n, int is_comp
     h->proto_taps.assign(taps, taps + (is_complex ? 2 * n : n));
     h->proto_complex = is_complex != 0;
     h->ntaps = n;
+    if (h->pfb_M) return pfb_upload_taps(h);
     return upload_taps(h);
 }
 
@@ -697,6 +704,9 @@ struct CallGeom {
 };
 
 static void fill_geom_gated(const sdr_handle* h, long long nitems, long long keep_c0, CallGeom& g);
+static int pfb_batch(sdr_handle* h, const void* iq, size_t n, size_t stride, int ncap, int is_dev, sdr_out* out);
+static int launch_back(sdr_handle* h, int ncap, const CallGeom& g, long long patch_off, long long nb_total, int fresh,
+                       int use_state_thr, int run_decoder);
 
 // channel filter (+ demod + slicer unless the output goes to the squelch stage)
 static int launch_front(sdr_handle* h, const float2* x, long long stride, long long n, int ncap,
@@ -855,6 +865,15 @@ static int launch_front_and_back(sdr_handle* h, const float2* x, long long strid
         hipLaunchKernelGGL(k_demod_slice, dim3(g.tiles, ncap), dim3(g.T), 0, h->stream, Q);
         HIPCHK(h, hipGetLastError());
     }
+    return launch_back(h, ncap, g, patch_off, nb_total, fresh, use_state_thr, run_decoder);
+}
+
+// run-length + decode over `ncap` rows of sliced bytes (k_backend); closes the profiling slot
+static int launch_back(sdr_handle* h, int ncap, const CallGeom& g, long long patch_off, long long nb_total, int fresh,
+                       int use_state_thr, int run_decoder)
+{
+    const sdr_chain_cfg& c = h->cfg;
+    const bool post = c.post_ntaps > 0;
     if (h->profile) HIPCHK(h, hipEventRecord(h->pev[3 * (h->pcount % SDR_PROF_RING) + 1], h->stream));
     if (c.demod == SDR_DEMOD_NONE || h->skip_slice) {
         if (h->profile) {
@@ -954,6 +973,7 @@ extern "C" int sdr_batch_process(sdr_handle* h, const void* iq, size_t n, size_t
                                  int is_dev, sdr_out* out)
 {
     if (!h || !iq || ncap < 1) return fail(h, SDR_E_ARG, "sdr_batch_process: bad argument");
+    if (h->pfb_M) return pfb_batch(h, iq, n, stride, ncap, is_dev, out);
     if (h->pre) {
         // upstream stage first; this stage then reads its complex output rows in place
         if (ncap > h->cfg.max_batch) return fail(h, SDR_E_CAPACITY, "sdr_batch_process: batch larger than the handle was created for");
@@ -1054,6 +1074,7 @@ static int stream_decode_step(sdr_handle* h, const CallGeom& g, const float2* x,
 extern "C" int sdr_process_iq(sdr_handle* h, const void* iq, size_t n, int is_dev, sdr_out* out)
 {
     if (!h || (!iq && n)) return fail(h, SDR_E_ARG, "sdr_process_iq: bad argument");
+    if (h->pfb_M) return fail(h, SDR_E_ARG, "sdr_process_iq: a channelizer handle takes whole captures (sdr_batch_process)");
     if (h->pre) {
         int r = sdr_process_iq(h->pre, iq, n, is_dev, nullptr);
         if (r) return fail(h, r, "prefilter: " + h->pre->err);
@@ -1348,7 +1369,7 @@ extern "C" int sdr_history_len(sdr_handle* h) { return h ? h->hist_len : SDR_E_A
 extern "C" int sdr_seek(sdr_handle* h, uint64_t abs_index, const void* halo, size_t n_halo, int is_dev)
 {
     if (!h) return fail(h, SDR_E_ARG, "sdr_seek: null handle");
-    if (h->pre || h->squelch_on || h->cfg.post_ntaps > 0 || h->prerotate)
+    if (h->pre || h->squelch_on || h->cfg.post_ntaps > 0 || h->prerotate || h->pfb_M)
         return fail(h, SDR_E_ARG, "sdr_seek: chains with a prefilter, squelch or post-demod filter cannot be positioned from a halo");
     const size_t H = (size_t)h->hist_len;
     const size_t need = abs_index < H ? (size_t)abs_index : H;
@@ -1417,6 +1438,7 @@ extern "C" int sdr_export_bits(sdr_handle* h, void* bits_dev, size_t cap_bytes, 
     return SDR_OK;
 }
 
+#include "pfb_host.h"
 #include "fm_host.h"
 #include "preamble_host.h"
 #include "selftest.h"

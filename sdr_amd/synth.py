@@ -347,6 +347,20 @@ def ook_iq(env, fs, f_off=0.0, amp=0.7, sigma=0.02, rng=None, phase0=0.0):
     return x.astype(np.complex64)
 
 
+def wideband_capture(n, fs, emitters, seed, sigma=0.02, amp=0.5):
+    """BASELINE.json configs[4] input: several OOK emitters at different carrier
+    offsets in one wideband capture.  emitters: [(f_off_hz, symbols, lead_in_us)].
+    Returns complex64[n]."""
+    rng = np.random.default_rng(seed)
+    x = sigma * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
+    t = np.arange(n, dtype=np.float64)
+    for f_off, sym, lead in emitters:
+        env = envelope(sym, fs, lead_in_us=lead, total=n)
+        ph = 2.0 * np.pi * (f_off / fs) * t + rng.random() * 2 * np.pi
+        x += amp * env * np.exp(1j * ph)
+    return x.astype(np.complex64)
+
+
 def ts33c_capture(n, fs, seed, f_off=0.0, n_frames=3, **fields):
     """One TS33C capture: `n_frames` repeats of one packet from 5 ms in."""
     rng = np.random.default_rng(seed)

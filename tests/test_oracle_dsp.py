@@ -185,3 +185,19 @@ def test_mag2_contract():
     x = _rng_iq(1000, 10)
     got = odsp.mag2(x)
     np.testing.assert_allclose(got, np.abs(x.astype(np.complex128)) ** 2, rtol=2e-7)
+
+
+def test_pfb_oracle_matches_bank_of_xlating_filters():
+    """orc_pfb_channelize == 64 x freq_xlating_fir_filter_ccc(decim 64, taps, c*fs/64)
+    within 1e-5 relative (different summation order), every channel."""
+    rng = np.random.default_rng(1)
+    M, fs = 64, 20e6
+    n = M * 200 + 17
+    x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+    taps = odsp.low_pass(1.0, fs, 100e3, 100e3)
+    assert taps.size == 481
+    y = odsp.pfb_channelize(x, taps, M)
+    assert y.shape == (M, n // M)
+    for c in range(M):
+        ref = odsp.freq_xlating_fir(x, taps, c * fs / M, fs, M)
+        assert np.max(np.abs(ref - y[c])) <= 1e-5 * np.max(np.abs(ref)), c
