@@ -192,6 +192,122 @@ def r_shape_workload(torch, dev, skip_cpu, ncap=64, n=1 << 19, fs=2e6, steps=20)
     return out
 
 
+def cu8_workload(torch, dev, iq, pkts, taps, steps=20):
+    """Secondary line: the headline batch quantised to rtl-sdr bytes (2 B per
+    sample instead of 8), converted while staged.  Same chain, same decoder."""
+    from sdr_amd import chain, _lib
+    ncap, n = iq.shape[0], iq.shape[1]
+    u8 = torch.empty((ncap, n, 2), dtype=torch.uint8, device=dev)
+    for a in range(0, ncap, 64):
+        u8[a:a + 64] = torch.clamp(torch.round(iq[a:a + 64] * 128.0 + 127.4), 0, 255).to(torch.uint8)
+    c = chain.Chain(FS, decim=DECIM, center_freq=F_OFF, taps=taps, decoder=chain.DEC_TS33C, max_batch=ncap,
+                    max_frames=4, max_samples=n, input_format="cu8")
+    c.set_stream(torch.cuda.current_stream().cuda_stream)
+    for _ in range(3):
+        c.batch_process(u8)
+    torch.cuda.synchronize()
+    c.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        c.batch_process(u8)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    front_ms, back_ms = c.profile_read()
+    got = {}
+    for f in c.fetch_frames():
+        if f.status == _lib.FRAME_OK:
+            got.setdefault(f.capture, []).append(f.packet())
+    n_ok = sum(1 for i in range(ncap) if got.get(i) == [pkts[i], pkts[i]])
+    if n_ok != ncap:
+        raise SystemExit("cu8: only %d of %d captures decoded to the transmitted packets" % (n_ok, ncap))
+    fk = float(np.mean(front_ms))
+    bps = 2.0 + 1.0 / DECIM
+    ach = bps * ncap * n / (fk * 1e-3) / 1e9
+    c.close()
+    return {"value": round(ncap * n / dt / 1e6, 1), "unit": "Msps", "ms_per_step": round(dt * 1e3, 4),
+            "captures": ncap, "samples_per_capture": n, "input": "cu8 (u8 I, u8 Q), (x-127.4)/128 while staging",
+            "roofline": {"bound": "hbm", "kernel": "k_frontend<true>", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                         "kernel_ms": round(fk, 4), "backend_kernel_ms": round(float(np.mean(back_ms)), 4),
+                         "bytes_per_launch": bps * ncap * n,
+                         "note": "2.02 algorithmic bytes per sample: at this sample rate the kernel is LDS/issue "
+                                 "bound, not HBM bound"},
+            "verified": "all captures decode to the transmitted packets"}
+
+
+def pfb_workload(torch, dev, skip_cpu, n=1 << 26, fs=20e6, steps=10):
+    """Secondary line (BASELINE.json configs[4]): one 2^26-sample wideband capture at 20 Msps
+    -> 64 sub-bands of 312.5 kHz (481-tap prototype, 8 per branch) -> mag^2 -> threshold ->
+    slicer -> keep_one_in_n(16) -> TS33C decoder on every channel."""
+    from sdr_amd import chain, synth, _lib
+    M, keep = 64, 16
+    rate = fs / M / keep
+    rng = np.random.default_rng(64)
+    pkt = synth.ts33c_packet(**synth.random_ts33c_fields(rng))
+    sym = []
+    for _ in range(3):
+        sym += synth.ts33c_symbols(synth.ts33c_bits(pkt), rng)
+    ch = 5
+    env = torch.from_numpy(synth.envelope(sym, fs, lead_in_us=5000.0, total=n)).to(dev)
+    g = torch.Generator(device=dev)
+    g.manual_seed(64)
+    iq = 0.02 * torch.randn((n, 2), generator=g, device=dev, dtype=torch.float32)
+    step_n = 1 << 22
+    for a in range(0, n, step_n):
+        t = torch.arange(a, a + step_n, dtype=torch.float64, device=dev)
+        ph = (2 * np.pi * ch / M) * t
+        e = env[a:a + step_n].to(torch.float32) * 0.5
+        iq[a:a + step_n, 0] += e * torch.cos(ph).to(torch.float32)
+        iq[a:a + step_n, 1] += e * torch.sin(ph).to(torch.float32)
+    del env
+    taps = chain.low_pass(1.0, fs, 100e3, 100e3)
+    c = chain.Chain(fs, taps=taps, keep_n=keep, decoder=chain.DEC_TS33C, decoder_rate=rate, max_samples=n,
+                    max_frames=64, channels=M)
+    c.set_stream(torch.cuda.current_stream().cuda_stream)
+    x = iq.reshape(1, n, 2)
+    for _ in range(3):
+        c.batch_process(x)
+    torch.cuda.synchronize()
+    c.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        c.batch_process(x)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    front_ms, back_ms = c.profile_read()
+    good = [f for f in c.fetch_frames() if f.status == _lib.FRAME_OK]
+    if [f.capture for f in good] != [ch] * len(good) or [f.packet() for f in good] != [pkt] * 3:
+        raise SystemExit("channelizer: expected the 3 transmitted frames in channel %d, got %s"
+                         % (ch, [(f.capture, f.packet().hex()) for f in good]))
+    fk = float(np.mean(front_ms))
+    bps = 8.0 + 1.0 / keep
+    ach = bps * n / (fk * 1e-3) / 1e9
+    out = {"value": round(n / dt / 1e6, 1), "unit": "Msps", "ms_per_step": round(dt * 1e3, 4), "samples": n,
+           "sample_rate": fs, "channels": M, "ntaps": int(taps.size), "keep_n": keep,
+           "chain": "pfb64->mag2->threshold->slicer->keep_one_in_n->ts33c_decoder per channel",
+           "roofline": {"bound": "hbm", "kernel": "k_pfb<8>", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                        "kernel_ms": round(fk, 4), "backend_kernel_ms": round(float(np.mean(back_ms)), 4),
+                        "bytes_per_launch": bps * n},
+           "verified": "the 3 transmitted frames decode in channel 5, no other channel yields a valid frame"}
+    if not skip_cpu:
+        from oracle import dsp as odsp
+        m = 1 << 21
+        xs = iq[:m].cpu().numpy().view(np.complex64).reshape(-1)
+        bits = c.fetch_bits().reshape(M, -1)
+        t0 = time.perf_counter()
+        y = odsp.pfb_channelize(xs, taps, M)
+        want = np.stack([odsp.slice_bits(odsp.mag2(y[k]), 1.0, 0.05, 0.15, keep)[0] for k in range(M)])
+        tc = time.perf_counter() - t0
+        if not np.array_equal(bits[:, :want.shape[1]], want):
+            raise SystemExit("channelizer: sliced bytes of the first 2^21 samples differ from the oracle")
+        out["cpu_baseline"] = {"value": round(m / tc / 1e6, 2), "unit": "Msps", "cores": 1, "kind": "port",
+                               "sample": "first 2^21 samples, oracle C channelizer + slicer, %.2f s" % tc}
+        out["verified"] += "; all 64 sliced streams of the first 2^21 samples bit-exact vs oracle"
+    c.close()
+    return out
+
+
 def pmc_traffic(ncap):
     """HBM bytes per k_frontend launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
     on this same command; counters cannot be read from inside the process).  None if the workload differs."""
@@ -326,10 +442,13 @@ def main():
         else:
             line["cpu_baseline"] = None
         if world == 1:
+            other = {"ook_batch_cu8": cu8_workload(torch, dev, iq, pkts, taps)}
             del iq
             torch.cuda.empty_cache()
-            line["other_workloads"] = {"fm_radio_wbfm": fm_workload(torch, dev, args.no_cpu_baseline),
-                                       "ook_r_shape_ts33c": r_shape_workload(torch, dev, args.no_cpu_baseline)}
+            other["fm_radio_wbfm"] = fm_workload(torch, dev, args.no_cpu_baseline)
+            other["ook_r_shape_ts33c"] = r_shape_workload(torch, dev, args.no_cpu_baseline)
+            other["wideband_pfb64"] = pfb_workload(torch, dev, args.no_cpu_baseline)
+            line["other_workloads"] = other
         print(json.dumps(line))
     c.close()
     if world > 1:

@@ -138,17 +138,11 @@ __device__ __forceinline__ void slice_tile(bool valid, float v, long long o, lon
 // then every thread walks its ntaps-window with ds_read_b64 + 2 (4) fmaf.
 // QUAD demod needs y[m-1]: thread t computes y[o0-1+t] and emits for t>=1.
 template <bool USE_LDS>
-__global__ void __launch_bounds__(256) k_frontend(FrontParams P)
+__device__ __forceinline__ void frontend_tile(const FrontParams& P, const int tile, const int cap, float2* lds, int* sh,
+                                              float2* ysh_static)
 {
-    extern __shared__ __align__(16) unsigned char smem_raw[];
-    float2* lds = reinterpret_cast<float2*>(smem_raw);
-    __shared__ int sh[12];
-    // discriminator history exchange: aliases the (by then consumed) tile when there is one
-    __shared__ float2 ysh_static[USE_LDS ? 1 : 256];
     float2* const ysh = USE_LDS ? lds : ysh_static;
-
     const int T = blockDim.x;
-    const int tile = blockIdx.x, cap = blockIdx.y;
     const int q = (P.demod == SDR_DEMOD_QUAD) ? 1 : 0;
     const long long o0 = (long long)tile * P.tile_out;
     const long long m_t0 = o0 - q;                       // FIR output index of thread 0
@@ -188,12 +182,15 @@ __global__ void __launch_bounds__(256) k_frontend(FrontParams P)
         if (P.in_fmt == SDR_IN_CU8 && P.vec_ok && !P.pre_tab) {
             // 2 B/sample: the tile's bytes go by DMA into a raw area behind the float
             // tile (16-B chunks = 8 samples, tile start moved down to a chunk boundary),
-            // then one pass converts them in place order.  Chunks that touch the
-            // capture's edges are converted from guarded loads instead.
-            unsigned char* raw = reinterpret_cast<unsigned char*>(lds + ((count + 2) & ~1));
+            // then every lane converts whole chunks: 16 bytes -> 8 complex floats, one
+            // v_cvt_f32_ubyteN + one fma per component (fma(u, 1/128, -127.4f/128) is the
+            // oracle's (u - 127.4f) * (1/128) exactly: both steps of that are exact).
+            // Chunks that touch the capture's edges are converted from guarded loads.
+            unsigned char* raw = reinterpret_cast<unsigned char*>(lds + ((count + 9) & ~1));
             const int off8 = (int)(gidx & 7);
             const long long lo8 = lo_idx - off8;
             const int chunks = (count + off8 + 7) >> 3;
+            lsh = off8;
             for (int c0 = (threadIdx.x & ~63); c0 < chunks; c0 += T) {
                 const int c = c0 + lane_id();
                 const long long s = lo8 + 8LL * c;
@@ -203,13 +200,26 @@ __global__ void __launch_bounds__(256) k_frontend(FrontParams P)
                         (__attribute__((address_space(3))) void*)(raw + 16 * c0), 16, 0, 0);
             }
             __syncthreads();
-            for (int i = threadIdx.x; i < count; i += T) {
-                const long long s = lo8 + 8LL * ((i + off8) >> 3);
+            const float kS = 0.0078125f, kC = -127.4f * 0.0078125f;
+            for (int c = threadIdx.x; c < chunks; c += T) {
+                const long long s = lo8 + 8LL * c;
+                float4* dst = reinterpret_cast<float4*>(lds + 8 * c);
                 if (s >= 0 && s + 8 <= P.n) {
-                    const uchar2 u = reinterpret_cast<const uchar2*>(raw)[i + off8];
-                    lds[i] = cu8_to_f2(u.x, u.y);
-                } else
-                    lds[i] = fetch(lo_idx + i);
+                    const uint4 r = *reinterpret_cast<const uint4*>(raw + 16 * c);
+                    const unsigned wd[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        float4 o;
+                        o.x = __builtin_fmaf((float)(wd[k] & 0xffu), kS, kC);
+                        o.y = __builtin_fmaf((float)((wd[k] >> 8) & 0xffu), kS, kC);
+                        o.z = __builtin_fmaf((float)((wd[k] >> 16) & 0xffu), kS, kC);
+                        o.w = __builtin_fmaf((float)(wd[k] >> 24), kS, kC);
+                        dst[k] = o;
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) lds[8 * c + k] = fetch(s + k);
+                }
             }
         } else if (P.in_fmt == SDR_IN_FC32 && P.vec_ok && !P.pre_tab) {
             // Every 16-B chunk that lies inside the capture goes by DMA; only the few
@@ -393,6 +403,16 @@ __global__ void __launch_bounds__(256) k_frontend(FrontParams P)
     slice_tile(valid, v, o, o - t, P.lo, P.hi, P.keep_n, P.keep_c0,
                P.bits + (long long)cap * P.bits_stride,
                P.tsum + (long long)cap * P.tiles_per_capture + tile, sh);
+}
+
+template <bool USE_LDS>
+__global__ void __launch_bounds__(256) k_frontend(FrontParams P)
+{
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    __shared__ int sh[12];
+    // discriminator history exchange: aliases the (by then consumed) tile when there is one
+    __shared__ float2 ysh_static[USE_LDS ? 1 : 256];
+    frontend_tile<USE_LDS>(P, blockIdx.x, blockIdx.y, reinterpret_cast<float2*>(smem_raw), sh, ysh_static);
 }
 
 // Real FIR (decimation 1) on demodulated floats + gain + slicer:

@@ -101,41 +101,43 @@ __global__ void __launch_bounds__(256) k_pfb(PfbParams Q)
     __syncthreads();
 
     // ---- phase 1: polyphase branch sums, lane = p ------------------------------------
-    float ar[PFB_TM], ai[PFB_TM];
+    // (re, im) pairs as 2-vectors: the fma / add / mul below are v_pk_*_f32, one
+    // instruction for both components, same IEEE result per component.
+    typedef float f2v __attribute__((ext_vector_type(2)));
+    f2v acc[PFB_TM];
 #pragma unroll
-    for (int i = 0; i < PFB_TM; ++i) ar[i] = ai[i] = 0.f;
-    const float2* col = lds + lsh + (long long)(PFB_TM * w) * PFB_M + (PFB_M - 1) - lane;
+    for (int i = 0; i < PFB_TM; ++i) acc[i] = f2v{0.f, 0.f};
+    const f2v* col = reinterpret_cast<const f2v*>(lds + lsh + (long long)(PFB_TM * w) * PFB_M + (PFB_M - 1) - lane);
 #pragma unroll
     for (int bb = 0; bb < PFB_TM + P - 1; ++bb) {
-        const float2 s = col[bb * PFB_M];
+        const f2v s = col[bb * PFB_M];
 #pragma unroll
         for (int q = 0; q < P; ++q) {
             const int i = bb - (P - 1) + q;   // compile-time after unrolling
-            if (i >= 0 && i < PFB_TM) {
-                ar[i] = __builtin_fmaf(hq[q], s.x, ar[i]);
-                ai[i] = __builtin_fmaf(hq[q], s.y, ai[i]);
-            }
+            if (i >= 0 && i < PFB_TM) acc[i] = __builtin_elementwise_fma(f2v{hq[q], hq[q]}, s, acc[i]);
         }
     }
 
     // ---- phase 2: 64-point DFT across the lanes ---------------------------------------
+    float ar[PFB_TM], ai[PFB_TM];
 #pragma unroll
     for (int i = 0; i < PFB_TM; ++i) {
-        float vr = ar[i], vi = ai[i];
+        f2v v = acc[i];
 #pragma unroll
         for (int s = 5; s >= 0; --s) {
             const int half = 1 << s;
-            const float pr = __shfl_xor(vr, half), pi = __shfl_xor(vi, half);
-            const float sr = vr + pr, si = vi + pi;
-            const float dr = pr - vr, di = pi - vi;
-            const float ur = __builtin_fmaf(dr, twl[s].x, -(di * twl[s].y));
-            const float ui = __builtin_fmaf(dr, twl[s].y, di * twl[s].x);
-            const bool upper = (lane & half) != 0;
-            vr = upper ? ur : sr;
-            vi = upper ? ui : si;
+            f2v pv;
+            pv.x = __shfl_xor(v.x, half);
+            pv.y = __shfl_xor(v.y, half);
+            const f2v sum = v + pv;
+            const f2v d = pv - v;
+            // (dr*wr - di*wi, dr*wi + di*wr) as fma(dr, (wr, wi), (-(di*wi), di*wr))
+            const f2v t = f2v{d.y, d.y} * f2v{-twl[s].y, twl[s].x};
+            const f2v u = __builtin_elementwise_fma(f2v{d.x, d.x}, f2v{twl[s].x, twl[s].y}, t);
+            v = (lane & half) ? u : sum;
         }
-        ar[i] = vr;
-        ai[i] = vi;
+        ar[i] = v.x;
+        ai[i] = v.y;
     }
 
     // ---- phase 3: lane = channel bitrev6(lane) -------------------------------------------
@@ -191,17 +193,31 @@ __global__ void __launch_bounds__(256) k_pfb(PfbParams Q)
         Q.tsum[row * Q.tiles_per_row + tile] = t;
     }
     int8_t* brow = Q.bits + row * Q.bits_stride;
+    if (Q.keep_n == 1) {   // keep_c0 == 0: the wave's 16 bytes are one aligned 16-B store
+        if (o_w + PFB_TM <= Q.nout) {
+            uint4 pk;
+            unsigned* pw = reinterpret_cast<unsigned*>(&pk);
 #pragma unroll
-    for (int i = 0; i < PFB_TM; ++i) {
-        const long long o = o_w + i;
-        if (o < Q.nout && o >= Q.keep_c0) {
-            const long long r = o - Q.keep_c0;
-            if (Q.keep_n == 1)
-                brow[r] = (int8_t)((states >> i) & 1u);
-            else {
-                const unsigned qq = (unsigned)r / (unsigned)Q.keep_n;   // r < 2^31: nout is bounded by the int32 TileSum index
-                if ((unsigned)r == qq * (unsigned)Q.keep_n) brow[qq] = (int8_t)((states >> i) & 1u);
+            for (int k = 0; k < 4; ++k) {
+                const unsigned nib = (states >> (4 * k)) & 0xfu;
+                pw[k] = (nib & 1u) | ((nib & 2u) << 7) | ((nib & 4u) << 14) | ((nib & 8u) << 21);
             }
+            *reinterpret_cast<uint4*>(brow + o_w) = pk;
+        } else {
+            for (int i = 0; i < PFB_TM && o_w + i < Q.nout; ++i) brow[o_w + i] = (int8_t)((states >> i) & 1u);
         }
+    } else if (o_w < Q.nout) {
+        // emitted outputs are those with (o - keep_c0) % keep_n == 0: one division per wave tile
+        // (o < 2^31: nout is bounded by the int32 TileSum index)
+        const unsigned kn = (unsigned)Q.keep_n;
+        long long o = o_w < Q.keep_c0 ? Q.keep_c0 : o_w;
+        const unsigned r = (unsigned)(o - Q.keep_c0);
+        unsigned q = r / kn;
+        if (q * kn != r) {
+            ++q;
+            o = Q.keep_c0 + (long long)q * kn;
+        }
+        const long long o_end = (o_w + PFB_TM < Q.nout) ? o_w + PFB_TM : Q.nout;
+        for (; o < o_end; o += kn, ++q) brow[q] = (int8_t)((states >> (int)(o - o_w)) & 1u);
     }
 }

@@ -347,7 +347,8 @@ static void pick_tile(const sdr_handle* h, int& T, size_t& lds, bool& use_lds)
     // +2: 16-B aligned tile start; cu8 input adds the raw byte area behind the float tile
     auto bytes = [&](int t) {
         const size_t count = (size_t)(t - 1) * D + nt;
-        return (count + 2) * sizeof(float2) + (h->in_fmt == SDR_IN_CU8 ? ((count + 14) / 8 + 1) * 16 : 0);
+        if (h->in_fmt == SDR_IN_CU8) return ((count + 9) & ~(size_t)1) * sizeof(float2) + ((count + 14) / 8 + 1) * 16;
+        return (count + 2) * sizeof(float2);
     };
     if (const char* e = getenv("SDR_TILE")) {  // tuning override: 64 | 128 | 256
         T = atoi(e);
