@@ -227,7 +227,8 @@ def cu8_workload(torch, dev, iq, pkts, taps, steps=20):
     return {"value": round(ncap * n / dt / 1e6, 1), "unit": "Msps", "ms_per_step": round(dt * 1e3, 4),
             "captures": ncap, "samples_per_capture": n, "input": "cu8 (u8 I, u8 Q), (x-127.4)/128 while staging",
             "roofline": {"bound": "hbm", "kernel": "k_frontend<true>", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                         "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                         "traffic": pmc_traffic("k_frontend<true> cu8", "captures_per_gpu=%d" % ncap)[0],
                          "kernel_ms": round(fk, 4), "backend_kernel_ms": round(float(np.mean(back_ms)), 4),
                          "bytes_per_launch": bps * ncap * n,
                          "note": "2.02 algorithmic bytes per sample: at this sample rate the kernel is LDS/issue "
@@ -286,7 +287,8 @@ def pfb_workload(torch, dev, skip_cpu, n=1 << 26, fs=20e6, steps=10):
            "sample_rate": fs, "channels": M, "ntaps": int(taps.size), "keep_n": keep,
            "chain": "pfb64->mag2->threshold->slicer->keep_one_in_n->ts33c_decoder per channel",
            "roofline": {"bound": "hbm", "kernel": "k_pfb<8>", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                        "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                        "traffic": pmc_traffic("k_pfb<8>", "samples=2^%d" % int(np.log2(n)))[0],
                         "kernel_ms": round(fk, 4), "backend_kernel_ms": round(float(np.mean(back_ms)), 4),
                         "bytes_per_launch": bps * n},
            "verified": "the 3 transmitted frames decode in channel 5, no other channel yields a valid frame"}
@@ -308,18 +310,19 @@ def pfb_workload(torch, dev, skip_cpu, n=1 << 26, fs=20e6, steps=10):
     return out
 
 
-def pmc_traffic(ncap):
-    """HBM bytes per k_frontend launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
-    on this same command; counters cannot be read from inside the process).  None if the workload differs."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_frontend.json")
+def pmc_traffic(kernel_key, workload_tag):
+    """HBM bytes per launch of one kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE over this same command; counters cannot be read from inside the process).  None if the
+    committed workload differs from the one being run."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_g_pmc.json")
     try:
         with open(path) as f:
-            rec = json.load(f)
-    except OSError:
+            rec = json.load(f)["kernels"][kernel_key]
+    except (OSError, KeyError, ValueError):
         return None, None
-    if "captures_per_gpu=%d" % ncap not in rec.get("workload", ""):
+    if workload_tag not in rec.get("workload", ""):
         return None, None
-    return int(rec["per_launch"]["hbm_bytes"]), "profiles/r01_pmc_frontend.json"
+    return int(rec["hbm_bytes"]), "profiles/r01_g_pmc.json"
 
 
 def main():
@@ -420,7 +423,7 @@ def main():
         fk = float(np.mean(front_ms)) if front_ms else float("nan")
         bk = float(np.mean(back_ms)) if back_ms else float("nan")
         achieved = BYTES_PER_SAMPLE * samples_per_step / (fk * 1e-3) / 1e9
-        traffic, traffic_src = pmc_traffic(ncap)
+        traffic, traffic_src = pmc_traffic("k_frontend<true> fc32", "captures_per_gpu=%d" % ncap)
         line = {
             "metric": "IQ Msps through filter+demod+slice+decode (whole job)",
             "value": round(value, 1), "unit": "Msps", "n_gpus": world, "steps": args.steps,
