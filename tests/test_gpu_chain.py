@@ -437,3 +437,47 @@ def test_mumbi_fs300_two_stage_chain(kat):
                 gb.append(c.fetch_bits())
             assert _assert_float_parity(np.concatenate(gv), wv[:iq.size // 10]) == 0
             assert np.array_equal(np.concatenate(gb), wb[:sum(x.size for x in gb)])
+
+
+def test_tfa_fsk_discriminator_chain():
+    """BASELINE.json configs[2] shape: 2-level FSK at 38400 Bd -> LPF (27 taps, TFA/decoder.grc:1163-1234)
+    -> quadrature_demod (TFA/decoder.grc:450-481) -> threshold -> slicer -> TFA stream decoder
+    (symbol length from the sync pairs, CRC-8).  The carrier idles on the "0" frequency so the
+    discriminator output has the gaps the decoder's reset_limit needs (the reference's own FSK tail
+    is disabled in the GRC; its working TFA decode is the mag^2 graph tested above)."""
+    fs, dev = 2e6, 60e3
+    rng = np.random.default_rng(38)
+    pkts, sym = [], []
+    for _ in range(2):
+        p = synth.tfa_packet(ident=int(rng.integers(0, 65536)), temp_c=float(rng.integers(-300, 500)) / 10,
+                             humidity=int(rng.integers(0, 100)))
+        pkts.append(p)
+        sym += synth.tfa_symbols(synth.tfa_bits(p), rng, reset_gap_us=900.0)
+    env = synth.envelope(sym, fs, lead_in_us=800.0)
+    env = np.concatenate([env, np.zeros(2500, np.uint8)]).astype(np.float64)
+    ph = 2 * np.pi * np.cumsum(dev * (2 * env - 1)) / fs
+    iq = (0.8 * np.exp(1j * ph) + 0.01 * (rng.standard_normal(env.size) + 1j * rng.standard_normal(env.size)))
+    iq = iq.astype(np.complex64)
+    taps = chain.low_pass(1, fs, 500e3, 250e3, chain.WIN_BLACKMAN)
+    gain = np.float32(fs / (2 * np.pi * dev))
+    with chain.Chain(fs, decim=1, taps=taps, demod=chain.DEMOD_QUAD, demod_gain=gain, thr=(-0.2, 0.2),
+                     tap_demod=True, decoder=chain.DEC_TFA_GRC, max_samples=iq.size) as c:
+        c.batch_process(iq[None, :])
+        v = c.fetch_demod()
+        bits = c.fetch_bits()
+        frames = c.fetch_frames()
+    want = odsp.quad_demod(odsp.fir_ccf(iq, taps, 1), gain)
+    assert _assert_float_parity(v, want) == 0
+    wb, _, _ = odsp.slice_bits(want, 1.0, -0.2, 0.2, 1)
+    assert np.array_equal(bits, wb)
+    # the start-up transient of the discriminator is a junk "packet": the GRC twin of the
+    # decoder reports it as "Symbol length error" (TFA/analyzer2.grc:959-960)
+    o = odec.TFAStreamDecoder(sample_rate=2000000, nan_guard=True)
+    o.work([wb])
+    assert len(frames) == len(o.frames)
+    for of, gf in zip(o.frames, frames):
+        if of["status"] == "Symbol length error":
+            assert gf.status == _lib.FRAME_SYMBOL_LENGTH
+        else:
+            assert_tfa_equal(of, gf)
+    assert [f.packet() for f in frames if f.status == 0] == pkts
