@@ -549,23 +549,29 @@ ORC_API int64_t orc_ook_chain(const float* iq, int64_t n, const float* taps, int
 }
 
 /* -------------------------------------------------- polyphase channelizer
- * BASELINE.json configs[4]: one wideband capture split into M equal sub-bands.
+ * BASELINE.json configs[4]: one wideband capture split into 64 equal sub-bands.
  * The reference has no channelizer block; the semantic
- * anchor is a bank of M freq_xlating_fir_filter_ccc(decim = M, taps,
- * center_freq = c*fs/M) blocks [GR-ext], restated above (orc_xlating_taps +
+ * anchor is a bank of 64 freq_xlating_fir_filter_ccc(decim = 64, taps,
+ * center_freq = c*fs/64) blocks [GR-ext], restated above (orc_xlating_taps +
  * orc_fir_ccc + rotation, which is the identity for these centre frequencies):
- *     y_c[m] = sum_k taps[k] e^{+j 2 pi c k / M} x[m M - k].
- * With k = p + q M this is a DFT over the polyphase branch sums
- *     v_p[m] = sum_q taps[p + q M] x[(m - q) M - p],   y_c[m] = sum_p W^{c p} v_p[m],
- * W = e^{+j 2 pi / M}.  tests/test_oracle_dsp.py checks this function against the
+ *     y_c[m] = sum_k taps[k] e^{+j 2 pi c k / 64} x[64 m - k].
+ * With k = p + 64 q this is a 64-point DFT over the polyphase branch sums
+ *     v_p[m] = sum_q taps[p + 64 q] x[64 (m - q) - p],   y_c[m] = sum_p W^{c p} v_p[m],
+ * W = e^{+j 2 pi / 64}.  tests/test_oracle_dsp.py checks this function against the
  * bank within 1e-5 relative; the HIP kernel reproduces THIS function bit for bit.
  *
  * Numeric contract: branch sums with one fmaf per tap, oldest sample first
- * (q descending); the DFT as a radix-2 decimation-in-frequency network over the
- * branch index, stages s = log2(M)-1 .. 0, partner = index ^ 2^s:
- *     lower' = a + b,  upper' = (a - b) * tw[(index mod 2^s) * M / 2^(s+1)]
- * with the complex product as (fmaf(dr, wr, -(di*wi)), fmaf(dr, wi, di*wr));
- * position l then holds channel bitrev(l).  tw[k] = (float cos, float sin)(2 pi k / M).
+ * (q descending).  DFT as 4 x 16 Cooley-Tukey, p = 16 a + b, c = e + 4 d:
+ *   1. for every b a radix-4 butterfly over a (W^16 = +j, no products):
+ *        s02 = v0+v2, d02 = v0-v2, s13 = v1+v3, d13 = v1-v3,
+ *        u0 = s02+s13, u2 = s02-s13, u1 = d02 + j d13, u3 = d02 - j d13;
+ *   2. z[e][b] = u_e * tw[(e b) mod 64] for e = 1..3 (z[0][b] = u0), complex product
+ *        (fmaf(dr, wr, -(di*wi)), fmaf(dr, wi, di*wr));
+ *   3. for every e a 16-point radix-2 decimation-in-frequency network over b,
+ *        stages half = 8,4,2,1: t[l] = a + b, t[l+half] = (a - b) * W16^k with
+ *        k = (l mod half) * 8/half, W16^k = tw[4k]; k = 0 -> no product, k = 4 ->
+ *        (-di, dr); position pos then holds d = bitrev4(pos).
+ * tw[k] = (float cos, float sin)(2 pi k / 64).
  * x: interleaved complex from stream start (samples before it are zero);
  * y: channel-major, y[2*(c*nout + m)]. */
 ORC_API void orc_pfb_twiddles(int M, float* tw)
@@ -576,14 +582,18 @@ ORC_API void orc_pfb_twiddles(int M, float* tw)
     }
 }
 
+static void orc_cmul(float dr, float di, float wr, float wi, float* orr, float* oi)
+{
+    *orr = fmaf(dr, wr, -(di * wi));
+    *oi = fmaf(dr, wi, di * wr);
+}
+
 ORC_API int orc_pfb_channelize(const float* x, int64_t n, const float* taps, int ntaps, int M,
                                const float* tw, int64_t nout, float* y)
 {
-    int lg = 0;
-    while ((1 << lg) < M) lg++;
-    if ((1 << lg) != M || M > 1024) return -1;
+    if (M != 64) return -1;
     const int P = (ntaps + M - 1) / M;
-    float vr[1024], vi[1024], ur[1024], ui[1024];
+    float vr[64], vi[64], zr[4][16], zi[4][16];
     for (int64_t m = 0; m < nout; m++) {
         for (int p = 0; p < M; p++) {
             float ar = 0.0f, ai = 0.0f;
@@ -597,30 +607,49 @@ ORC_API int orc_pfb_channelize(const float* x, int64_t n, const float* taps, int
             vr[p] = ar;
             vi[p] = ai;
         }
-        for (int s = lg - 1; s >= 0; s--) {
-            const int half = 1 << s;
-            for (int l = 0; l < M; l++) {
-                const int pr = l ^ half;
-                if (!(l & half)) {
-                    ur[l] = vr[l] + vr[pr];
-                    ui[l] = vi[l] + vi[pr];
-                } else {
-                    float dr = vr[pr] - vr[l], di = vi[pr] - vi[l];
-                    int e = (l & (half - 1)) * (M / (2 * half));
-                    float wr = tw[2 * e], wi = tw[2 * e + 1];
-                    ur[l] = fmaf(dr, wr, -(di * wi));
-                    ui[l] = fmaf(dr, wi, di * wr);
-                }
+        for (int b = 0; b < 16; b++) {
+            float s02r = vr[b] + vr[32 + b], s02i = vi[b] + vi[32 + b];
+            float d02r = vr[b] - vr[32 + b], d02i = vi[b] - vi[32 + b];
+            float s13r = vr[16 + b] + vr[48 + b], s13i = vi[16 + b] + vi[48 + b];
+            float d13r = vr[16 + b] - vr[48 + b], d13i = vi[16 + b] - vi[48 + b];
+            float ur[4], ui[4];
+            ur[0] = s02r + s13r; ui[0] = s02i + s13i;
+            ur[2] = s02r - s13r; ui[2] = s02i - s13i;
+            ur[1] = d02r - d13i; ui[1] = d02i + d13r;
+            ur[3] = d02r + d13i; ui[3] = d02i - d13r;
+            zr[0][b] = ur[0];
+            zi[0][b] = ui[0];
+            for (int e = 1; e < 4; e++) {
+                int k = (e * b) & 63;
+                orc_cmul(ur[e], ui[e], tw[2 * k], tw[2 * k + 1], &zr[e][b], &zi[e][b]);
             }
-            memcpy(vr, ur, sizeof(float) * M);
-            memcpy(vi, ui, sizeof(float) * M);
         }
-        for (int l = 0; l < M; l++) {
-            int c = 0;
-            for (int b = 0; b < lg; b++)
-                if (l & (1 << b)) c |= 1 << (lg - 1 - b);
-            y[2 * (c * nout + m)] = vr[l];
-            y[2 * (c * nout + m) + 1] = vi[l];
+        for (int e = 0; e < 4; e++) {
+            float* tr = zr[e];
+            float* ti = zi[e];
+            for (int half = 8; half >= 1; half >>= 1)
+                for (int l = 0; l < 16; l++) {
+                    if (l & half) continue;
+                    float ar = tr[l], ai = ti[l], br = tr[l + half], bi = ti[l + half];
+                    tr[l] = ar + br;
+                    ti[l] = ai + bi;
+                    float dr = ar - br, di = ai - bi;
+                    int k = (l & (half - 1)) * (8 / half);
+                    if (k == 0) {
+                        tr[l + half] = dr;
+                        ti[l + half] = di;
+                    } else if (k == 4) {
+                        tr[l + half] = -di;
+                        ti[l + half] = dr;
+                    } else
+                        orc_cmul(dr, di, tw[8 * k], tw[8 * k + 1], &tr[l + half], &ti[l + half]);
+                }
+            for (int pos = 0; pos < 16; pos++) {
+                int d = ((pos & 1) << 3) | ((pos & 2) << 1) | ((pos & 4) >> 1) | ((pos & 8) >> 3);
+                int c = e + 4 * d;
+                y[2 * (c * nout + m)] = tr[pos];
+                y[2 * (c * nout + m) + 1] = ti[pos];
+            }
         }
     }
     return 0;

@@ -114,7 +114,8 @@ static int pfb_batch(sdr_handle* h, const void* iq, size_t n, size_t stride, int
         Q.tap_stride = h->tap_stride;
         Q.tsum = h->d_tsum;
         Q.tiles_per_row = g.tiles;
-        const size_t lds = ((size_t)(h->pfb_P + PFB_TILE - 1) * PFB_M + 2) * sizeof(float2);
+        size_t lds = ((size_t)(h->pfb_P + PFB_TILE - 1) * PFB_M + 2) * sizeof(float2);
+        if (lds < (size_t)PFB_NW * PFB_SLAB * sizeof(float2)) lds = (size_t)PFB_NW * PFB_SLAB * sizeof(float2);
         dim3 grid(g.tiles, ncap), block(256);
         switch (h->pfb_P) {
         case 4: hipLaunchKernelGGL(k_pfb<4>, grid, block, lds, h->stream, Q); break;

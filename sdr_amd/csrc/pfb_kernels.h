@@ -11,13 +11,19 @@
 //
 // Work split: a 256-thread workgroup owns 64 consecutive output times of one
 // capture; its (P+63)*64 input samples are staged once in LDS by 16-B DMA.
-// Wave w owns times 16w..16w+15.  Phase 1: lane = branch p; the lane keeps 16
-// complex accumulators and walks the 15+P sample blocks of its column once
-// (conflict-free ds_read_b64, every sample reused for up to P outputs).
-// Phase 2: the DFT over p runs across lanes (radix-2 DIF, partner = lane ^ 2^s by
-// DPP/bpermute); lane l ends up holding channel bitrev6(l).  Phase 3: lane =
-// channel; hysteresis over its 16 outputs in registers, carry across the four
-// waves through LDS, one TileSum per (channel, workgroup) for k_backend.
+// Wave w owns times 16w..16w+15 and, once the samples are consumed, a private
+// 8.5 KB slab of the same LDS for three in-wave transposes:
+//   phase 1  lane = branch p: 16 complex accumulators, the lane's column walked once
+//            (conflict-free ds_read_b64, every sample reused for up to P outputs);
+//   T1       V[time][p] -> quad layout: 4 lanes per output time, lane r of the quad
+//            takes b = r mod 4;
+//   phase 2a radix-4 butterflies over a (p = 16a + b) + twiddles, all in registers;
+//   T2       U[time][e][b] -> lane e of the quad takes all 16 b;
+//   phase 2b 16-point FFT in registers (no cross-lane traffic, every butterfly
+//            output is used);
+//   T3       Y[channel][time] -> lane = channel c = e + 4d;
+//   phase 3  hysteresis over the lane's 16 outputs in registers, carry across the
+//            four waves through LDS, one TileSum per (channel, workgroup).
 #pragma once
 #include "sdr_common.h"
 #include "frontend_kernels.h"
@@ -26,6 +32,9 @@
 #define PFB_TM 16    // output times per wave
 #define PFB_NW 4     // waves per workgroup
 #define PFB_TILE (PFB_TM * PFB_NW)
+#define PFB_VP 68     // row pitch (float2) of the V/U transposes: 16 rows per wave
+#define PFB_YP 17     // row pitch of the Y transpose: 64 rows per wave
+#define PFB_SLAB (PFB_TM * PFB_VP)   // == PFB_M * PFB_YP float2 per wave
 
 struct PfbParams {
     const float2* x;        // capture 0, sample 0
@@ -95,53 +104,114 @@ __global__ void __launch_bounds__(256) k_pfb(PfbParams Q)
     float hq[P];
 #pragma unroll
     for (int q = 0; q < P; ++q) hq[q] = Q.taps[lane + PFB_M * q];
-    float2 twl[6];
+    typedef float f2v __attribute__((ext_vector_type(2)));
+    const int qi = lane >> 2, r = lane & 3;   // quad layout: output time 16w + qi, quarter r
+    f2v twq[3][4];                            // W^(e*b), e = 1..3, b = 4j + r
 #pragma unroll
-    for (int s = 0; s < 6; ++s) twl[s] = Q.tw[(lane & ((1 << s) - 1)) << (5 - s)];
+    for (int e = 1; e < 4; ++e)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float2 t = Q.tw[(e * (4 * j + r)) & 63];
+            twq[e - 1][j] = f2v{t.x, t.y};
+        }
     __syncthreads();
 
     // ---- phase 1: polyphase branch sums, lane = p ------------------------------------
     // (re, im) pairs as 2-vectors: the fma / add / mul below are v_pk_*_f32, one
     // instruction for both components, same IEEE result per component.
-    typedef float f2v __attribute__((ext_vector_type(2)));
     f2v acc[PFB_TM];
 #pragma unroll
     for (int i = 0; i < PFB_TM; ++i) acc[i] = f2v{0.f, 0.f};
-    const f2v* col = reinterpret_cast<const f2v*>(lds + lsh + (long long)(PFB_TM * w) * PFB_M + (PFB_M - 1) - lane);
+    {
+        const f2v* col = reinterpret_cast<const f2v*>(lds + lsh + (long long)(PFB_TM * w) * PFB_M + (PFB_M - 1) - lane);
 #pragma unroll
-    for (int bb = 0; bb < PFB_TM + P - 1; ++bb) {
-        const f2v s = col[bb * PFB_M];
+        for (int bb = 0; bb < PFB_TM + P - 1; ++bb) {
+            const f2v s = col[bb * PFB_M];
 #pragma unroll
-        for (int q = 0; q < P; ++q) {
-            const int i = bb - (P - 1) + q;   // compile-time after unrolling
-            if (i >= 0 && i < PFB_TM) acc[i] = __builtin_elementwise_fma(f2v{hq[q], hq[q]}, s, acc[i]);
+            for (int q = 0; q < P; ++q) {
+                const int i = bb - (P - 1) + q;   // compile-time after unrolling
+                if (i >= 0 && i < PFB_TM) acc[i] = __builtin_elementwise_fma(f2v{hq[q], hq[q]}, s, acc[i]);
+            }
         }
     }
+    auto cmul = [](f2v d, f2v wv) -> f2v {   // (dr*wr - di*wi, dr*wi + di*wr), the oracle's orc_cmul
+        const f2v t = f2v{d.y, d.y} * f2v{-wv.y, wv.x};
+        return __builtin_elementwise_fma(f2v{d.x, d.x}, wv, t);
+    };
+    __syncthreads();   // every wave is done with the samples: their LDS is reused below
+    f2v* slab = reinterpret_cast<f2v*>(lds) + w * PFB_SLAB;
 
-    // ---- phase 2: 64-point DFT across the lanes ---------------------------------------
+    // ---- T1: V[time][p] ------------------------------------------------------------------
+#pragma unroll
+    for (int i = 0; i < PFB_TM; ++i) slab[i * PFB_VP + lane] = acc[i];
+    __syncthreads();
+
+    // ---- phase 2a: radix-4 over a (p = 16a + b) + twiddle, b = 4j + r -----------------------
+    f2v* vrow = slab + qi * PFB_VP;
+    f2v z[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int b = 4 * j + r;
+        const f2v v0 = vrow[b], v1 = vrow[16 + b], v2 = vrow[32 + b], v3 = vrow[48 + b];
+        const f2v s02 = v0 + v2, d02 = v0 - v2, s13 = v1 + v3, d13 = v1 - v3;
+        z[0][j] = s02 + s13;
+        const f2v u1 = f2v{d02.x - d13.y, d02.y + d13.x};
+        const f2v u2 = s02 - s13;
+        const f2v u3 = f2v{d02.x + d13.y, d02.y - d13.x};
+        z[1][j] = cmul(u1, twq[0][j]);
+        z[2][j] = cmul(u2, twq[1][j]);
+        z[3][j] = cmul(u3, twq[2][j]);
+    }
+    // ---- T2: U[time][e][b]; a lane reads and writes only positions = r mod 4 of its row,
+    // so no barrier is needed between the reads above and these writes
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) vrow[16 * e + 4 * j + r] = z[e][j];
+    __syncthreads();
+
+    // ---- phase 2b: 16-point DFT over b in registers, lane r of the quad = e -------------------
+    f2v t[16];
+#pragma unroll
+    for (int b = 0; b < 16; ++b) t[b] = vrow[16 * r + b];
+#pragma unroll
+    for (int s = 3; s >= 0; --s) {
+        const int half = 1 << s;
+#pragma unroll
+        for (int l = 0; l < 16; ++l) {
+            if (l & half) continue;
+            const f2v a = t[l], bb = t[l + half];
+            t[l] = a + bb;
+            const f2v d = a - bb;
+            const int k = (l & (half - 1)) * (8 / half);
+            if (k == 0)
+                t[l + half] = d;
+            else if (k == 4)
+                t[l + half] = f2v{-d.y, d.x};
+            else {
+                const float2 wv = Q.tw[4 * k];
+                t[l + half] = cmul(d, f2v{wv.x, wv.y});
+            }
+        }
+    }
+    __syncthreads();   // the wave has read its U rows: the slab becomes Y[channel][time]
+    // ---- T3: position pos holds d = bitrev4(pos); channel c = e + 4d ----------------------------
+#pragma unroll
+    for (int pos = 0; pos < 16; ++pos) {
+        const int d = ((pos & 1) << 3) | ((pos & 2) << 1) | ((pos & 4) >> 1) | ((pos & 8) >> 3);
+        slab[(r + 4 * d) * PFB_YP + qi] = t[pos];
+    }
+    __syncthreads();
     float ar[PFB_TM], ai[PFB_TM];
 #pragma unroll
     for (int i = 0; i < PFB_TM; ++i) {
-        f2v v = acc[i];
-#pragma unroll
-        for (int s = 5; s >= 0; --s) {
-            const int half = 1 << s;
-            f2v pv;
-            pv.x = __shfl_xor(v.x, half);
-            pv.y = __shfl_xor(v.y, half);
-            const f2v sum = v + pv;
-            const f2v d = pv - v;
-            // (dr*wr - di*wi, dr*wi + di*wr) as fma(dr, (wr, wi), (-(di*wi), di*wr))
-            const f2v t = f2v{d.y, d.y} * f2v{-twl[s].y, twl[s].x};
-            const f2v u = __builtin_elementwise_fma(f2v{d.x, d.x}, f2v{twl[s].x, twl[s].y}, t);
-            v = (lane & half) ? u : sum;
-        }
-        ar[i] = v.x;
-        ai[i] = v.y;
+        const f2v y = slab[lane * PFB_YP + i];
+        ar[i] = y.x;
+        ai[i] = y.y;
     }
 
-    // ---- phase 3: lane = channel bitrev6(lane) -------------------------------------------
-    const int ch = (int)(__brev((unsigned)lane) >> 26);
+    // ---- phase 3: lane = channel ------------------------------------------------------------
+    const int ch = lane;
     const long long row = (long long)cap * PFB_M + ch;
     const long long o_w = m0 + PFB_TM * w;   // first output index of this wave
     if (Q.demod == SDR_DEMOD_NONE) {
