@@ -64,8 +64,20 @@ __global__ void __launch_bounds__(256) k_pfb(PfbParams Q)
     __shared__ int sh_first[PFB_NW][PFB_M];   // first event of the wave's 16 outputs (0..15) or -1
     __shared__ int sh_last[PFB_NW][PFB_M];
 
-    const int tile = blockIdx.x, cap = blockIdx.y;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    // XCD-aware tile order: workgroups go round-robin over the 8 XCDs (each with its
+    // own L2), so blockIdx.x = 8*idx + k is mapped to the idx-th tile of the k-th
+    // contiguous eighth of the capture.  Neighbouring tiles then share an L2: the
+    // (P-1)*64-sample halo is an L2 hit and the 4 bytes a tile adds to each channel
+    // row merge into full lines before they leave the L2.
+    const int cap = blockIdx.y;
+    int tile;
+    {
+        const int nt = gridDim.x, k = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        const int base = nt >> 3, rem = nt & 7;
+        tile = k * base + (k < rem ? k : rem) + idx;
+    }
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: guards on it are scalar branches
     const long long m0 = (long long)tile * PFB_TILE;
     const float2* __restrict__ x = Q.x + (long long)cap * Q.stride;
     const long long lo_idx = (m0 - (P - 1)) * PFB_M - (PFB_M - 1);

@@ -1,0 +1,16 @@
+"""Scratch: the channelizer kernel alone (for rocprofv3 --pmc passes)."""
+import sys, os, numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from sdr_amd import chain
+dev = torch.device("cuda", 0)
+n = 1 << 26
+fs = 20e6
+iq = torch.randn((1, n, 2), device=dev, dtype=torch.float32) * 0.1
+taps = chain.low_pass(1.0, fs, 100e3, 100e3)
+c = chain.Chain(fs, taps=taps, keep_n=16, decoder=chain.DEC_NONE, max_samples=n, channels=64)
+c.profile_enable(True)
+for _ in range(8):
+    c.batch_process(iq)
+f, b = c.profile_read()
+ms = np.mean(f[2:])
+print("k_pfb %.4f ms  %.0f GB/s" % (ms, 8.0625 * n / ms / 1e6))
