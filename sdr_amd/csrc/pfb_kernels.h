@@ -18,7 +18,7 @@
 //   T1       V[time][p] -> quad layout: 4 lanes per output time, lane r of the quad
 //            takes b = r mod 4;
 //   phase 2a radix-4 butterflies over a (p = 16a + b) + twiddles, all in registers;
-//   T2       U[time][e][b] -> lane e of the quad takes all 16 b;
+//   T2       U[time][e][b] (bank-swizzled) -> lane e of the quad takes all 16 b;
 //   phase 2b 16-point FFT in registers (no cross-lane traffic, every butterfly
 //            output is used);
 //   T3       Y[channel][time] -> lane = channel c = e + 4d;
@@ -176,16 +176,20 @@ __global__ void __launch_bounds__(256) k_pfb(PfbParams Q)
     }
     // ---- T2: U[time][e][b]; a lane reads and writes only positions = r mod 4 of its row,
     // so no barrier is needed between the reads above and these writes
+    // Row layout pos(e, b) = 16e + 4(b>>2) + ((b + e) & 3): a Latin square in (e, b mod 4),
+    // so both the writes (lanes differ in r = b mod 4) and the reads below (lanes differ
+    // in e) spread over the banks; the plain 16e + b layout made the reads 4-way conflicts.
+    // All T1 reads of the wave precede these writes in program order.
 #pragma unroll
     for (int e = 0; e < 4; ++e)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) vrow[16 * e + 4 * j + r] = z[e][j];
+        for (int j = 0; j < 4; ++j) vrow[16 * e + 4 * j + ((r + e) & 3)] = z[e][j];
     __syncthreads();
 
     // ---- phase 2b: 16-point DFT over b in registers, lane r of the quad = e -------------------
     f2v t[16];
 #pragma unroll
-    for (int b = 0; b < 16; ++b) t[b] = vrow[16 * r + b];
+    for (int b = 0; b < 16; ++b) t[b] = vrow[16 * r + 4 * (b >> 2) + ((b + r) & 3)];
 #pragma unroll
     for (int s = 3; s >= 0; --s) {
         const int half = 1 << s;
