@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsdrhip.so")
+LIB_PATH = os.environ.get("SDR_LIB_PATH") or os.path.join(_HERE, "libsdrhip.so")  # env override: tuning experiments only
 
 SDR_OK, SDR_E_ARG, SDR_E_HIP, SDR_E_CAPACITY, SDR_E_OVERFLOW, SDR_E_NODEVICE = 0, -1, -2, -3, -4, -5
 

@@ -161,7 +161,7 @@ __global__ void __launch_bounds__(256) k_frontend_mfma(FrontParams P)
                 if (s >= 0 && s + 2 <= P.n)
                     __builtin_amdgcn_global_load_lds(
                         (const __attribute__((address_space(1))) void*)(x + s),
-                        (__attribute__((address_space(3))) void*)(smp + 4 * c0), 16, 0, 0);
+                        (__attribute__((address_space(3))) void*)(smp + 4 * c0), 16, 0, SDR_GLDS_AUX);
                 else {
                     *reinterpret_cast<float2*>(smp + 4 * c) = fetch(s);
                     *reinterpret_cast<float2*>(smp + 4 * c + 2) = fetch(s + 1);

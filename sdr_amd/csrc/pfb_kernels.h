@@ -101,7 +101,7 @@ __global__ void __launch_bounds__(256) k_pfb(PfbParams Q)
                 const long long s = lo_al + 2LL * p;
                 if (s >= 0 && s + 2 <= Q.n)
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(x + s),
-                                                     (__attribute__((address_space(3))) void*)(lds + 2 * p0), 16, 0, 0);
+                                                     (__attribute__((address_space(3))) void*)(lds + 2 * p0), 16, 0, SDR_GLDS_AUX);
                 else {
                     lds[2 * p] = fetch(s);
                     lds[2 * p + 1] = fetch(s + 1);

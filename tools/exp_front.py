@@ -9,8 +9,8 @@ iq = torch.randn((ncap, bench.N_PER_CAPTURE, 2), device=dev, dtype=torch.float32
 taps = chain.low_pass(1.0, bench.FS, 20e3, 40e3)
 c = chain.Chain(bench.FS, decim=50, center_freq=bench.F_OFF, taps=taps, decoder=chain.DEC_NONE, max_batch=ncap, max_frames=4, max_samples=bench.N_PER_CAPTURE)
 c.profile_enable(True)
-for _ in range(12):
+for _ in range(60):
     c.batch_process(iq)
 f, b = c.profile_read()
-ms = np.mean(f[2:])
+ms = np.mean(f[10:])
 print("SDR_DBG=%s front %.4f ms  %.0f GB/s" % (os.environ.get("SDR_DBG", "0"), ms, 8.02 * ncap * bench.N_PER_CAPTURE / ms / 1e6))
