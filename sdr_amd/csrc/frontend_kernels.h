@@ -145,8 +145,8 @@ __device__ __forceinline__ void slice_tile(bool valid, float v, long long o, lon
 // then every thread walks its ntaps-window with ds_read_b64 + 2 (4) fmaf.
 // QUAD demod needs y[m-1]: thread t computes y[o0-1+t] and emits for t>=1.
 template <bool USE_LDS>
-__device__ __forceinline__ void frontend_tile(const FrontParams& P, const int tile, const int cap, float2* lds, int* sh,
-                                              float2* ysh_static)
+__device__ __forceinline__ void frontend_tile(const FrontParams& P, const FrontKTaps& KT, const int tile, const int cap,
+                                              float2* lds, int* sh, float2* ysh_static)
 {
     float2* const ysh = USE_LDS ? lds : ysh_static;
     const int T = blockDim.x;
@@ -279,6 +279,54 @@ __device__ __forceinline__ void frontend_tile(const FrontParams& P, const int ti
         const float2* p = lds + lsh + (long long)t * P.D;
         const int lane = lane_id();
         const bool cplx = P.taps_complex != 0;
+        if (P.ktaps_n > 0) {
+            // <= 64 taps: they live in the kernel-argument segment, the compiler fetches them
+            // with s_load (uniform address, constant memory) straight into SGPR operands of
+            // the fmas: no VGPR, no v_readlane, no LDS traffic for taps.
+            const int nt = P.ntaps;
+            int j = 0;
+            if (cplx) {
+                for (; j + 8 <= nt; j += 8) {
+                    float2 s[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) s[u] = p[j + u];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const float a = KT.t[j + u].x, b = KT.t[j + u].y;
+                        ar = __builtin_fmaf(a, s[u].x, ar);
+                        ar = __builtin_fmaf(-b, s[u].y, ar);
+                        ai = __builtin_fmaf(a, s[u].y, ai);
+                        ai = __builtin_fmaf(b, s[u].x, ai);
+                    }
+                }
+                for (; j < nt; ++j) {
+                    const float2 s = p[j];
+                    const float a = KT.t[j].x, b = KT.t[j].y;
+                    ar = __builtin_fmaf(a, s.x, ar);
+                    ar = __builtin_fmaf(-b, s.y, ar);
+                    ai = __builtin_fmaf(a, s.y, ai);
+                    ai = __builtin_fmaf(b, s.x, ai);
+                }
+            } else {
+                for (; j + 8 <= nt; j += 8) {
+                    float2 s[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) s[u] = p[j + u];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const float a = KT.t[j + u].x;
+                        ar = __builtin_fmaf(a, s[u].x, ar);
+                        ai = __builtin_fmaf(a, s[u].y, ai);
+                    }
+                }
+                for (; j < nt; ++j) {
+                    const float2 s = p[j];
+                    const float a = KT.t[j].x;
+                    ar = __builtin_fmaf(a, s.x, ar);
+                    ai = __builtin_fmaf(a, s.y, ai);
+                }
+            }
+        } else {
         float tr = 0.f, ti = 0.f;
         if (lane < P.ntaps) {
             if (cplx) {
@@ -350,6 +398,7 @@ __device__ __forceinline__ void frontend_tile(const FrontParams& P, const int ti
             tr = ntr;
             ti = nti;
         }
+        }
         if (!have_y) {
             ar = 0.f;
             ai = 0.f;
@@ -413,13 +462,13 @@ __device__ __forceinline__ void frontend_tile(const FrontParams& P, const int ti
 }
 
 template <bool USE_LDS>
-__global__ void __launch_bounds__(256) k_frontend(FrontParams P)
+__global__ void __launch_bounds__(256) k_frontend(FrontParams P, FrontKTaps KT)
 {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     __shared__ int sh[12];
     // discriminator history exchange: aliases the (by then consumed) tile when there is one
     __shared__ float2 ysh_static[USE_LDS ? 1 : 256];
-    frontend_tile<USE_LDS>(P, blockIdx.x, blockIdx.y, reinterpret_cast<float2*>(smem_raw), sh, ysh_static);
+    frontend_tile<USE_LDS>(P, KT, blockIdx.x, blockIdx.y, reinterpret_cast<float2*>(smem_raw), sh, ysh_static);
 }
 
 // Real FIR (decimation 1) on demodulated floats + gain + slicer:

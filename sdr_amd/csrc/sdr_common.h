@@ -46,6 +46,7 @@ struct FrontParams {
     int ntaps;
     int taps_complex;
     const float* rtaps;     // taps reversed (oldest-sample-first order); (re,im) pairs if complex
+    int ktaps_n;            // >0: the same reversed taps also sit in ktaps (kernel-argument segment -> scalar loads)
     unsigned long long nco_inc;
     unsigned long long nco_m0;  // absolute output index of output 0 (NCO phase origin)
     const float2* nco_tab;  // nullptr = no rotation
@@ -62,6 +63,11 @@ struct FrontParams {
     TileSum* tsum;
     int tiles_per_capture;
     int tile_out;           // demod outputs per tile
+};
+
+#define SDR_KTAPS 64
+struct FrontKTaps {          // second kernel argument of k_frontend<true>: <= 64 reversed taps, (re, im) pairs (im = 0 for real taps)
+    float2 t[SDR_KTAPS];
 };
 
 struct PostParams {         // real FIR on demodulated floats + slicer (TFA/analyzer2.grc chain)

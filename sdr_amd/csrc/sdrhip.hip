@@ -34,6 +34,8 @@ struct sdr_handle {
     int ntaps = 1;
     bool rt_complex = false;
     float* d_rtaps = nullptr;
+    FrontKTaps ktaps;        // the same reversed taps for the kernel-argument path (ntaps <= 64)
+    int ktaps_n = 0;
     std::vector<float> post_taps;
     float* d_post_rtaps = nullptr;
     float2* d_nco_tab = nullptr;
@@ -309,6 +311,15 @@ static int upload_taps(sdr_handle* h)
         h->rt_complex = false;
         rt.resize(n);
         for (int k = 0; k < n; ++k) rt[n - 1 - k] = h->proto_taps[k];
+    }
+    memset(&h->ktaps, 0, sizeof h->ktaps);
+    h->ktaps_n = 0;
+    if (n <= SDR_KTAPS && !getenv("SDR_NO_KTAPS")) {
+        for (int k = 0; k < n; ++k) {
+            h->ktaps.t[k].x = h->rt_complex ? rt[2 * k] : rt[k];
+            h->ktaps.t[k].y = h->rt_complex ? rt[2 * k + 1] : 0.0f;
+        }
+        h->ktaps_n = n;
     }
     if (h->d_rtaps) (void)hipFree(h->d_rtaps);
     h->d_rtaps = nullptr;
@@ -730,6 +741,7 @@ static int launch_front(sdr_handle* h, const float2* x, long long stride, long l
     P.ntaps = h->ntaps;
     P.taps_complex = h->rt_complex;
     P.rtaps = h->d_rtaps;
+    P.ktaps_n = h->ktaps_n;
     P.nco_inc = h->nco_inc;
     P.nco_m0 = h->out_count;
     P.nco_tab = (c.center_freq != 0.0 && !h->prerotate) ? h->d_nco_tab : nullptr;
@@ -764,9 +776,9 @@ static int launch_front(sdr_handle* h, const float2* x, long long stride, long l
     if (g.mfma)
         hipLaunchKernelGGL(k_frontend_mfma, grid, block, g.lds, h->stream, P);
     else if (g.use_lds)
-        hipLaunchKernelGGL(k_frontend<true>, grid, block, g.lds, h->stream, P);
+        hipLaunchKernelGGL(k_frontend<true>, grid, block, g.lds, h->stream, P, h->ktaps);
     else
-        hipLaunchKernelGGL(k_frontend<false>, grid, block, 0, h->stream, P);
+        hipLaunchKernelGGL(k_frontend<false>, grid, block, 0, h->stream, P, h->ktaps);
     HIPCHK(h, hipGetLastError());
     if (post && !to_squelch) {
         // the post filter has its own tiling: one output per thread, 256 per tile
