@@ -226,7 +226,7 @@ def cu8_workload(torch, dev, iq, pkts, taps, steps=20):
     c.close()
     return {"value": round(ncap * n / dt / 1e6, 1), "unit": "Msps", "ms_per_step": round(dt * 1e3, 4),
             "captures": ncap, "samples_per_capture": n, "input": "cu8 (u8 I, u8 Q), (x-127.4)/128 while staging",
-            "roofline": {"bound": "hbm", "kernel": "k_frontend<true>", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "k_frontend<true, true>", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                          "traffic": pmc_traffic("k_frontend<true> cu8", "captures_per_gpu=%d" % ncap)[0],
                          "kernel_ms": round(fk, 4), "backend_kernel_ms": round(float(np.mean(back_ms)), 4),
@@ -434,7 +434,7 @@ def main():
                        "samples_per_capture": N_PER_CAPTURE, "sample_rate": FS, "ntaps": int(taps.size),
                        "decim": DECIM, "center_freq": F_OFF, "chain": "xlating_fir->mag2->threshold->slicer->ts33c_decoder",
                        "parallelism": "captures sharded per GPU, RCCL all_gather of frame records" if world > 1 else "1 GPU"},
-            "roofline": {"bound": "hbm", "kernel": "k_frontend<true>", "achieved": round(achieved, 1),
+            "roofline": {"bound": "hbm", "kernel": "k_frontend<true, false>", "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": traffic, "traffic_source": traffic_src, "kernel_ms": round(fk, 4), "backend_kernel_ms": round(bk, 4),
                          "bytes_per_launch": BYTES_PER_SAMPLE * samples_per_step},

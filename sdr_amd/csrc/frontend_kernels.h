@@ -144,7 +144,7 @@ __device__ __forceinline__ void slice_tile(bool valid, float v, long long o, lon
 // (T-1)*D + ntaps input samples are staged once in LDS (coalesced 8-B loads),
 // then every thread walks its ntaps-window with ds_read_b64 + 2 (4) fmaf.
 // QUAD demod needs y[m-1]: thread t computes y[o0-1+t] and emits for t>=1.
-template <bool USE_LDS>
+template <bool USE_LDS, bool CU8>
 __device__ __forceinline__ void frontend_tile(const FrontParams& P, const FrontKTaps& KT, const int tile, const int cap,
                                               float2* lds, int* sh, float2* ysh_static)
 {
@@ -161,7 +161,7 @@ __device__ __forceinline__ void frontend_tile(const FrontParams& P, const FrontK
     // rtl-sdr bytes: the same two exact float ops as the oracle's cu8_to_fc32
     const uchar2* __restrict__ xb = reinterpret_cast<const uchar2*>(P.x) + (long long)cap * P.stride;
     auto fetch = [&](long long idx) -> float2 {
-        if (P.in_fmt == SDR_IN_CU8) {
+        if (CU8) {
             uchar2 u;
             if (idx >= 0) {
                 if (idx >= P.n) return make_float2(0.f, 0.f);
@@ -186,7 +186,7 @@ __device__ __forceinline__ void frontend_tile(const FrontParams& P, const FrontK
         const int odd = (int)(gidx & 1);
         const long long lo_al = lo_idx - odd;
         const int pairs = (count + odd + 1) >> 1;
-        if (P.in_fmt == SDR_IN_CU8 && P.vec_ok && !P.pre_tab) {
+        if (CU8 && P.vec_ok && !P.pre_tab) {
             // 2 B/sample: the tile's bytes go by DMA into a raw area behind the float
             // tile (16-B chunks = 8 samples, tile start moved down to a chunk boundary),
             // then every lane converts whole chunks: 16 bytes -> 8 complex floats, one
@@ -204,7 +204,7 @@ __device__ __forceinline__ void frontend_tile(const FrontParams& P, const FrontK
                 if (c < chunks && s >= 0 && s + 8 <= P.n)
                     __builtin_amdgcn_global_load_lds(
                         (const __attribute__((address_space(1))) void*)(xb + s),
-                        (__attribute__((address_space(3))) void*)(raw + 16 * c0), 16, 0, 0);
+                        (__attribute__((address_space(3))) void*)(raw + 16 * c0), 16, 0, SDR_GLDS_AUX);
             }
             __syncthreads();
             const float kS = 0.0078125f, kC = -127.4f * 0.0078125f;
@@ -228,21 +228,28 @@ __device__ __forceinline__ void frontend_tile(const FrontParams& P, const FrontK
                     for (int k = 0; k < 8; ++k) lds[8 * c + k] = fetch(s + k);
                 }
             }
-        } else if (P.in_fmt == SDR_IN_FC32 && P.vec_ok && !P.pre_tab) {
+        } else if (!CU8 && P.vec_ok && !P.pre_tab) {
             // Every 16-B chunk that lies inside the capture goes by DMA; only the few
             // chunks that touch the capture's edges (zero padding / streaming history)
             // are fetched by their lanes with guarded loads.  (First and last tile of a
             // capture used to take a fully guarded, serialised staging loop.)
+            // Two loops on purpose: with the guarded fetches in the same loop body the
+            // compiler may merge the paths and wait (vmcnt(0)) after every DMA, which
+            // serialises the staging (seen: 0.46 -> 1.24 ms).  The DMA loop holds no
+            // other memory operation.
             lsh = odd;
             for (int p0 = (threadIdx.x & ~63); p0 < pairs; p0 += T) {
                 const int p = p0 + lane_id();
-                if (p < pairs) {
+                const long long s = lo_al + 2LL * p;
+                if (p < pairs && s >= 0 && s + 2 <= P.n)
+                    __builtin_amdgcn_global_load_lds(
+                        (const __attribute__((address_space(1))) void*)(x + s),
+                        (__attribute__((address_space(3))) void*)(lds + 2 * p0), 16, 0, SDR_GLDS_AUX);
+            }
+            if (lo_al < 0 || lo_al + 2LL * pairs > P.n) {   // uniform: only edge tiles have guarded chunks
+                for (int p = threadIdx.x; p < pairs; p += T) {
                     const long long s = lo_al + 2LL * p;
-                    if (s >= 0 && s + 2 <= P.n)
-                        __builtin_amdgcn_global_load_lds(
-                            (const __attribute__((address_space(1))) void*)(x + s),
-                            (__attribute__((address_space(3))) void*)(lds + 2 * p0), 16, 0, SDR_GLDS_AUX);
-                    else {
+                    if (!(s >= 0 && s + 2 <= P.n)) {
                         lds[2 * p] = fetch(s);
                         lds[2 * p + 1] = fetch(s + 1);
                     }
@@ -461,14 +468,16 @@ __device__ __forceinline__ void frontend_tile(const FrontParams& P, const FrontK
                P.tsum + (long long)cap * P.tiles_per_capture + tile, sh);
 }
 
-template <bool USE_LDS>
+// CU8 = the input is rtl-sdr bytes (sdr_set_input_format): a kernel of its own so that the
+// complex64 path carries none of the conversion code (and profiles list the two apart).
+template <bool USE_LDS, bool CU8 = false>
 __global__ void __launch_bounds__(256) k_frontend(FrontParams P, FrontKTaps KT)
 {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     __shared__ int sh[12];
     // discriminator history exchange: aliases the (by then consumed) tile when there is one
     __shared__ float2 ysh_static[USE_LDS ? 1 : 256];
-    frontend_tile<USE_LDS>(P, KT, blockIdx.x, blockIdx.y, reinterpret_cast<float2*>(smem_raw), sh, ysh_static);
+    frontend_tile<USE_LDS, CU8>(P, KT, blockIdx.x, blockIdx.y, reinterpret_cast<float2*>(smem_raw), sh, ysh_static);
 }
 
 // Real FIR (decimation 1) on demodulated floats + gain + slicer:

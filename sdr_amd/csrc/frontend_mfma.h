@@ -152,17 +152,23 @@ __global__ void __launch_bounds__(256) k_frontend_mfma(FrontParams P)
         // padding / streaming history) by guarded loads of their own lanes
         const int per = 8 * D + 1;                         // LDS chunks per pad block (last one is the pad)
         const int nlds = nsrc + nsrc / (8 * D) + 1;
+        // (two loops: the DMA loop holds no other memory operation, see k_frontend)
         for (int c0 = (t & ~63); c0 < nlds; c0 += T) {
             const int c = c0 + lane;
             const int blk = c / per, r = c - blk * per;
             const int sc = blk * 8 * D + r;
-            if (c < nlds && r < 8 * D && sc < nsrc) {
+            const long long s = lo_al + 2LL * sc;
+            if (c < nlds && r < 8 * D && sc < nsrc && s >= 0 && s + 2 <= P.n)
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void*)(x + s),
+                    (__attribute__((address_space(3))) void*)(smp + 4 * c0), 16, 0, SDR_GLDS_AUX);
+        }
+        if (lo_al < 0 || lo_al + 2LL * nsrc > P.n) {   // uniform: only edge tiles have guarded chunks
+            for (int c = t; c < nlds; c += T) {
+                const int blk = c / per, r = c - blk * per;
+                const int sc = blk * 8 * D + r;
                 const long long s = lo_al + 2LL * sc;
-                if (s >= 0 && s + 2 <= P.n)
-                    __builtin_amdgcn_global_load_lds(
-                        (const __attribute__((address_space(1))) void*)(x + s),
-                        (__attribute__((address_space(3))) void*)(smp + 4 * c0), 16, 0, SDR_GLDS_AUX);
-                else {
+                if (r < 8 * D && sc < nsrc && !(s >= 0 && s + 2 <= P.n)) {
                     *reinterpret_cast<float2*>(smp + 4 * c) = fetch(s);
                     *reinterpret_cast<float2*>(smp + 4 * c + 2) = fetch(s + 1);
                 }

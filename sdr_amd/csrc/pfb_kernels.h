@@ -95,14 +95,18 @@ __global__ void __launch_bounds__(256) k_pfb(PfbParams Q)
         const long long lo_al = lo_idx - odd;
         const int pairs = (count + odd + 1) >> 1;
         lsh = odd;
+        // (two loops: the DMA loop holds no other memory operation, see k_frontend)
         for (int p0 = (threadIdx.x & ~63); p0 < pairs; p0 += 256) {
             const int p = p0 + lane;
-            if (p < pairs) {
+            const long long s = lo_al + 2LL * p;
+            if (p < pairs && s >= 0 && s + 2 <= Q.n)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(x + s),
+                                                 (__attribute__((address_space(3))) void*)(lds + 2 * p0), 16, 0, SDR_GLDS_AUX);
+        }
+        if (lo_al < 0 || lo_al + 2LL * pairs > Q.n) {   // uniform: only edge tiles have guarded chunks
+            for (int p = threadIdx.x; p < pairs; p += 256) {
                 const long long s = lo_al + 2LL * p;
-                if (s >= 0 && s + 2 <= Q.n)
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(x + s),
-                                                     (__attribute__((address_space(3))) void*)(lds + 2 * p0), 16, 0, SDR_GLDS_AUX);
-                else {
+                if (!(s >= 0 && s + 2 <= Q.n)) {
                     lds[2 * p] = fetch(s);
                     lds[2 * p + 1] = fetch(s + 1);
                 }

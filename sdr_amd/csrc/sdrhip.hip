@@ -775,10 +775,15 @@ static int launch_front(sdr_handle* h, const float2* x, long long stride, long l
     dim3 grid(g.tiles, ncap), block(g.T);
     if (g.mfma)
         hipLaunchKernelGGL(k_frontend_mfma, grid, block, g.lds, h->stream, P);
-    else if (g.use_lds)
-        hipLaunchKernelGGL(k_frontend<true>, grid, block, g.lds, h->stream, P, h->ktaps);
+    else if (h->in_fmt == SDR_IN_CU8) {
+        if (g.use_lds)
+            hipLaunchKernelGGL((k_frontend<true, true>), grid, block, g.lds, h->stream, P, h->ktaps);
+        else
+            hipLaunchKernelGGL((k_frontend<false, true>), grid, block, 0, h->stream, P, h->ktaps);
+    } else if (g.use_lds)
+        hipLaunchKernelGGL((k_frontend<true, false>), grid, block, g.lds, h->stream, P, h->ktaps);
     else
-        hipLaunchKernelGGL(k_frontend<false>, grid, block, 0, h->stream, P, h->ktaps);
+        hipLaunchKernelGGL((k_frontend<false, false>), grid, block, 0, h->stream, P, h->ktaps);
     HIPCHK(h, hipGetLastError());
     if (post && !to_squelch) {
         // the post filter has its own tiling: one output per thread, 256 per tile
