@@ -228,7 +228,7 @@ def cu8_workload(torch, dev, iq, pkts, taps, steps=20):
             "captures": ncap, "samples_per_capture": n, "input": "cu8 (u8 I, u8 Q), (x-127.4)/128 while staging",
             "roofline": {"bound": "hbm", "kernel": "k_frontend<true, true>", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                         "traffic": pmc_traffic("k_frontend<true> cu8", "captures_per_gpu=%d" % ncap)[0],
+                         "traffic": pmc_traffic("k_frontend<true, true> cu8", "captures_per_gpu=%d" % ncap)[0],
                          "kernel_ms": round(fk, 4), "backend_kernel_ms": round(float(np.mean(back_ms)), 4),
                          "bytes_per_launch": bps * ncap * n,
                          "note": "2.02 algorithmic bytes per sample: at this sample rate the kernel is LDS/issue "
@@ -314,7 +314,7 @@ def pmc_traffic(kernel_key, workload_tag):
     """HBM bytes per launch of one kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
     WRITE_SIZE over this same command; counters cannot be read from inside the process).  None if the
     committed workload differs from the one being run."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_g_pmc.json")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_i_pmc.json")
     try:
         with open(path) as f:
             rec = json.load(f)["kernels"][kernel_key]
@@ -322,7 +322,7 @@ def pmc_traffic(kernel_key, workload_tag):
         return None, None
     if workload_tag not in rec.get("workload", ""):
         return None, None
-    return int(rec["hbm_bytes"]), "profiles/r01_g_pmc.json"
+    return int(rec["hbm_bytes"]), "profiles/r01_i_pmc.json"
 
 
 def main():
@@ -423,7 +423,7 @@ def main():
         fk = float(np.mean(front_ms)) if front_ms else float("nan")
         bk = float(np.mean(back_ms)) if back_ms else float("nan")
         achieved = BYTES_PER_SAMPLE * samples_per_step / (fk * 1e-3) / 1e9
-        traffic, traffic_src = pmc_traffic("k_frontend<true> fc32", "captures_per_gpu=%d" % ncap)
+        traffic, traffic_src = pmc_traffic("k_frontend<true, false> fc32", "captures_per_gpu=%d" % ncap)
         line = {
             "metric": "IQ Msps through filter+demod+slice+decode (whole job)",
             "value": round(value, 1), "unit": "Msps", "n_gpus": world, "steps": args.steps,
