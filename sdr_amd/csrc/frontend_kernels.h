@@ -146,7 +146,7 @@ __device__ __forceinline__ void slice_tile(bool valid, float v, long long o, lon
 // QUAD demod needs y[m-1]: thread t computes y[o0-1+t] and emits for t>=1.
 template <bool USE_LDS, bool CU8>
 __device__ __forceinline__ void frontend_tile(const FrontParams& P, const FrontKTaps& KT, const int tile, const int cap,
-                                              float2* lds, int* sh, float2* ysh_static)
+                                              float2* lds, int* sh, float2* ysh_static, const int staged_lsh = -1)
 {
     float2* const ysh = USE_LDS ? lds : ysh_static;
     const int T = blockDim.x;
@@ -178,7 +178,9 @@ __device__ __forceinline__ void frontend_tile(const FrontParams& P, const FrontK
     };
 
     int lsh = 0;  // LDS index of sample lo_idx
-    if (USE_LDS) {
+    if (USE_LDS && staged_lsh >= 0) {
+        lsh = staged_lsh;   // the caller (k_frontend_pipe) has staged the tile and synchronised
+    } else if (USE_LDS) {
         // Interior tiles: 16-B direct-to-LDS loads (global_load_lds_dwordx4), no
         // VGPR round trip, one 1-KiB piece per wave-instruction.  The tile start is
         // moved down to a 16-B boundary of the capture buffer.
@@ -186,49 +188,7 @@ __device__ __forceinline__ void frontend_tile(const FrontParams& P, const FrontK
         const int odd = (int)(gidx & 1);
         const long long lo_al = lo_idx - odd;
         const int pairs = (count + odd + 1) >> 1;
-        if (CU8 && P.vec_ok && !P.pre_tab) {
-            // 2 B/sample: the tile's bytes go by DMA into a raw area behind the float
-            // tile (16-B chunks = 8 samples, tile start moved down to a chunk boundary),
-            // then every lane converts whole chunks: 16 bytes -> 8 complex floats, one
-            // v_cvt_f32_ubyteN + one fma per component (fma(u, 1/128, -127.4f/128) is the
-            // oracle's (u - 127.4f) * (1/128) exactly: both steps of that are exact).
-            // Chunks that touch the capture's edges are converted from guarded loads.
-            unsigned char* raw = reinterpret_cast<unsigned char*>(lds + ((count + 9) & ~1));
-            const int off8 = (int)(gidx & 7);
-            const long long lo8 = lo_idx - off8;
-            const int chunks = (count + off8 + 7) >> 3;
-            lsh = off8;
-            for (int c0 = (threadIdx.x & ~63); c0 < chunks; c0 += T) {
-                const int c = c0 + lane_id();
-                const long long s = lo8 + 8LL * c;
-                if (c < chunks && s >= 0 && s + 8 <= P.n)
-                    __builtin_amdgcn_global_load_lds(
-                        (const __attribute__((address_space(1))) void*)(xb + s),
-                        (__attribute__((address_space(3))) void*)(raw + 16 * c0), 16, 0, SDR_GLDS_AUX);
-            }
-            __syncthreads();
-            const float kS = 0.0078125f, kC = -127.4f * 0.0078125f;
-            for (int c = threadIdx.x; c < chunks; c += T) {
-                const long long s = lo8 + 8LL * c;
-                float4* dst = reinterpret_cast<float4*>(lds + 8 * c);
-                if (s >= 0 && s + 8 <= P.n) {
-                    const uint4 r = *reinterpret_cast<const uint4*>(raw + 16 * c);
-                    const unsigned wd[4] = {r.x, r.y, r.z, r.w};
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        float4 o;
-                        o.x = __builtin_fmaf((float)(wd[k] & 0xffu), kS, kC);
-                        o.y = __builtin_fmaf((float)((wd[k] >> 8) & 0xffu), kS, kC);
-                        o.z = __builtin_fmaf((float)((wd[k] >> 16) & 0xffu), kS, kC);
-                        o.w = __builtin_fmaf((float)(wd[k] >> 24), kS, kC);
-                        dst[k] = o;
-                    }
-                } else {
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) lds[8 * c + k] = fetch(s + k);
-                }
-            }
-        } else if (!CU8 && P.vec_ok && !P.pre_tab) {
+        if (!CU8 && P.vec_ok && !P.pre_tab) {
             // Every 16-B chunk that lies inside the capture goes by DMA; only the few
             // chunks that touch the capture's edges (zero padding / streaming history)
             // are fetched by their lanes with guarded loads.  (First and last tile of a
@@ -468,8 +428,9 @@ __device__ __forceinline__ void frontend_tile(const FrontParams& P, const FrontK
                P.tsum + (long long)cap * P.tiles_per_capture + tile, sh);
 }
 
-// CU8 = the input is rtl-sdr bytes (sdr_set_input_format): a kernel of its own so that the
-// complex64 path carries none of the conversion code (and profiles list the two apart).
+// CU8 = the input is rtl-sdr bytes (sdr_set_input_format).  Aligned cu8 batches and calls
+// run on k_frontend_pipe below; this instantiation is the general path (unaligned buffers,
+// pre-rotation), staging through guarded per-sample fetches.
 template <bool USE_LDS, bool CU8 = false>
 __global__ void __launch_bounds__(256) k_frontend(FrontParams P, FrontKTaps KT)
 {
@@ -478,6 +439,129 @@ __global__ void __launch_bounds__(256) k_frontend(FrontParams P, FrontKTaps KT)
     // discriminator history exchange: aliases the (by then consumed) tile when there is one
     __shared__ float2 ysh_static[USE_LDS ? 1 : 256];
     frontend_tile<USE_LDS, CU8>(P, KT, blockIdx.x, blockIdx.y, reinterpret_cast<float2*>(smem_raw), sh, ysh_static);
+}
+
+// Register-staged form, the default for cu8 input: the tile's bytes come in as plain
+// 16-B global loads (NCH chunks per lane, register array with static indexing; chunk =
+// 8 cu8 samples or 2 complex64 samples) and are converted on the way into the float
+// tile -- no raw LDS area, so cu8 gets the same 128-output tile as complex64 input
+// (the DMA variant needed 64 KB for it and fell back to 64 outputs).  A workgroup may
+// walk `tpw` consecutive tiles with the next tile's loads in flight while the current
+// one is filtered; measured, that never pays here (cu8 headline batch: tpw 1 -> 0.353 ms,
+// 2 -> 0.414, 4 -> 0.447, 8 -> 0.543; complex64: 0.58 ms against 0.455 ms for the DMA
+// kernel), so tpw defaults to 1 and complex64 stays on k_frontend's LDS DMA.  Chunks
+// that touch the capture's edges (zero padding, streaming history) take guarded
+// per-sample fetches in a loop of their own.
+template <bool CU8, int NCH>
+__global__ void __launch_bounds__(256) k_frontend_pipe(FrontParams P, FrontKTaps KT, int tpw)
+{
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    float2* lds = reinterpret_cast<float2*>(smem_raw);
+    __shared__ int sh[12];
+    __shared__ float2 ysh_static[1];
+    constexpr int SPC = CU8 ? 8 : 2;   // samples per 16-B chunk
+    const int T = blockDim.x, tid = threadIdx.x, cap = blockIdx.y;
+    const int q = (P.demod == SDR_DEMOD_QUAD) ? 1 : 0;
+    const int H = P.ntaps - 1;
+    const int count = (T - 1) * P.D + P.ntaps;
+    const char* __restrict__ xbytes = reinterpret_cast<const char*>(P.x) + (long long)cap * P.stride * (CU8 ? 2 : 8);
+    const float2* __restrict__ x = P.x + (long long)cap * P.stride;
+    const uchar2* __restrict__ xb = reinterpret_cast<const uchar2*>(P.x) + (long long)cap * P.stride;
+    auto fetch = [&](long long idx) -> float2 {
+        if (CU8) {
+            uchar2 u;
+            if (idx >= 0) {
+                if (idx >= P.n) return make_float2(0.f, 0.f);
+                u = xb[idx];
+            } else if (P.hist && idx >= -(long long)P.hist_len)
+                u = reinterpret_cast<const uchar2*>(P.hist)[P.hist_len + idx];
+            else
+                return make_float2(0.f, 0.f);
+            return cu8_to_f2(u.x, u.y);
+        }
+        if (idx >= 0) return idx < P.n ? x[idx] : make_float2(0.f, 0.f);
+        if (P.hist && idx >= -(long long)P.hist_len) return P.hist[P.hist_len + idx];
+        return make_float2(0.f, 0.f);
+    };
+    // Per tile (all wave-uniform): lo = first sample of the tile's chunk grid (chunk-aligned in
+    // the capture buffer), off = lo_idx - lo, nch = chunks, [c_in0, c_in1) = chunks that lie
+    // wholly inside the capture (they go through the registers; the rest are edge chunks).
+    struct TileGeo {
+        long long lo;
+        int off, nch, c_in0, c_in1;
+    };
+    auto geo = [&](int tile) -> TileGeo {
+        TileGeo g;
+        const long long lo_idx = P.in0 + ((long long)tile * P.tile_out - q) * P.D - H;
+        g.off = (int)(((long long)cap * P.stride + lo_idx) & (SPC - 1));
+        g.lo = lo_idx - g.off;
+        g.nch = (count + g.off + SPC - 1) / SPC;
+        long long a = g.lo < 0 ? (-g.lo + SPC - 1) / SPC : 0;            // first chunk with s >= 0
+        long long b = P.n - g.lo < 0 ? 0 : (P.n - g.lo) / SPC;            // chunks with s + SPC <= n
+        if (a > g.nch) a = g.nch;
+        if (b > g.nch) b = g.nch;
+        if (b < a) b = a;
+        g.c_in0 = (int)a;
+        g.c_in1 = (int)b;
+        return g;
+    };
+    const int tile0 = blockIdx.x * tpw;
+    int tile1 = tile0 + tpw;
+    if (tile1 > P.tiles_per_capture) tile1 = P.tiles_per_capture;
+
+    uint4 r[NCH];
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) r[k] = make_uint4(0u, 0u, 0u, 0u);
+    auto issue = [&](const TileGeo& g) {
+        const char* tb = xbytes + g.lo * (CU8 ? 2 : 8);   // uniform base, 32-bit lane offsets
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            const int c = k * T + tid;
+            if (c >= g.c_in0 && c < g.c_in1) r[k] = *reinterpret_cast<const uint4*>(tb + 16u * (unsigned)c);
+        }
+    };
+    TileGeo gcur;
+    if (tile0 < tile1) {
+        gcur = geo(tile0);
+        issue(gcur);
+    }
+    for (int tile = tile0; tile < tile1; ++tile) {
+        const TileGeo g = gcur;
+        // registers -> float tile (sample s sits at lds[s - lo])
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            const int c = k * T + tid;
+            if (c >= g.c_in0 && c < g.c_in1) {
+                if (CU8) {
+                    const float kS = 0.0078125f, kC = -127.4f * 0.0078125f;
+                    const unsigned wd[4] = {r[k].x, r[k].y, r[k].z, r[k].w};
+                    float4* dst = reinterpret_cast<float4*>(lds + 8 * c);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float4 o;
+                        o.x = __builtin_fmaf((float)(wd[j] & 0xffu), kS, kC);
+                        o.y = __builtin_fmaf((float)((wd[j] >> 8) & 0xffu), kS, kC);
+                        o.z = __builtin_fmaf((float)((wd[j] >> 16) & 0xffu), kS, kC);
+                        o.w = __builtin_fmaf((float)(wd[j] >> 24), kS, kC);
+                        dst[j] = o;
+                    }
+                } else
+                    *reinterpret_cast<uint4*>(lds + 2 * c) = r[k];
+            }
+        }
+        if (g.c_in0 > 0 || g.c_in1 < g.nch) {   // uniform: edge tiles only
+            for (int c = tid; c < g.nch; c += T)
+                if (c < g.c_in0 || c >= g.c_in1)
+                    for (int j = 0; j < SPC; ++j) lds[SPC * c + j] = fetch(g.lo + (long long)c * SPC + j);
+        }
+        if (tile + 1 < tile1) {   // next tile's bytes: in flight while this tile is filtered
+            gcur = geo(tile + 1);
+            issue(gcur);
+        }
+        __syncthreads();
+        frontend_tile<true, CU8>(P, KT, tile, cap, lds, sh, ysh_static, g.off);
+        __syncthreads();   // the tile and sh[] are reused by the next round
+    }
 }
 
 // Real FIR (decimation 1) on demodulated floats + gain + slicer:

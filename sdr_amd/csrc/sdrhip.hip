@@ -87,6 +87,8 @@ struct sdr_handle {
     float2* d_pfb_tw = nullptr;
     int in_fmt = SDR_IN_FC32;   // sample format of this stage's input (sdr_set_input_format)
     size_t ss() const { return in_fmt == SDR_IN_CU8 ? 2 : sizeof(float2); }  // bytes per input sample
+    int pipe_mode = 1;   // k_frontend_pipe: 0 never, 1 for cu8 input (default), 2 for complex64 too (env SDR_PIPE; measured slower there)
+    int pipe_tpw = 1;    // tiles per workgroup in that kernel (env SDR_TPW); measured on cu8: 1 -> 0.353 ms, 2 -> 0.414, 4 -> 0.447, 8 -> 0.543
     int front_mode = 0;  // 0 auto, 1 LDS/VALU kernel only, 2 MFMA kernel whenever it fits (env SDR_FRONTEND=auto|valu|mfma)
 
     // internal modes used by the FM chain (fm_host.h)
@@ -355,12 +357,8 @@ static void pick_tile(const sdr_handle* h, int& T, size_t& lds, bool& use_lds)
     const int D = h->cfg.decim, nt = h->ntaps;
     const int cands[3] = {256, 128, 64};
     use_lds = true;
-    // +2: 16-B aligned tile start; cu8 input adds the raw byte area behind the float tile
-    auto bytes = [&](int t) {
-        const size_t count = (size_t)(t - 1) * D + nt;
-        if (h->in_fmt == SDR_IN_CU8) return ((count + 9) & ~(size_t)1) * sizeof(float2) + ((count + 14) / 8 + 1) * 16;
-        return (count + 2) * sizeof(float2);
-    };
+    // +2: 16-B aligned tile start
+    auto bytes = [&](int t) { return ((size_t)(t - 1) * D + nt + 2) * sizeof(float2); };
     if (const char* e = getenv("SDR_TILE")) {  // tuning override: 64 | 128 | 256
         T = atoi(e);
         lds = bytes(T);
@@ -473,6 +471,8 @@ extern "C" int sdr_create(const sdr_chain_cfg* cfg, sdr_handle** out)
     }
     if (const char* fm = getenv("SDR_FRONTEND"))
         h->front_mode = !strcmp(fm, "valu") ? 1 : (!strcmp(fm, "mfma") ? 2 : 0);
+    if (const char* pe = getenv("SDR_PIPE")) h->pipe_mode = atoi(pe);
+    if (const char* pe = getenv("SDR_TPW")) h->pipe_tpw = atoi(pe) > 0 ? atoi(pe) : 1;
     (void)hipDeviceGetAttribute(&h->num_cus, hipDeviceAttributeMultiprocessorCount, h->device);
     if (h->num_cus < 1) h->num_cus = 256;
     int rc = SDR_OK;
@@ -713,6 +713,8 @@ struct CallGeom {
     size_t lds;
     bool use_lds;
     bool mfma;   // k_frontend_mfma: T = 64*nw threads, 256*nw FIR outputs per tile
+    int pipe_nch = 0;  // >0: k_frontend_pipe with this many 16-B chunks per lane per tile
+    int pipe_tpw = 0;  // tiles per workgroup
 };
 
 static void fill_geom_gated(const sdr_handle* h, long long nitems, long long keep_c0, CallGeom& g);
@@ -775,7 +777,18 @@ static int launch_front(sdr_handle* h, const float2* x, long long stride, long l
     dim3 grid(g.tiles, ncap), block(g.T);
     if (g.mfma)
         hipLaunchKernelGGL(k_frontend_mfma, grid, block, g.lds, h->stream, P);
-    else if (h->in_fmt == SDR_IN_CU8) {
+    else if (g.pipe_nch && P.vec_ok && !P.pre_tab) {
+        dim3 pgrid((g.tiles + g.pipe_tpw - 1) / g.pipe_tpw, ncap);
+        const bool cu8 = h->in_fmt == SDR_IN_CU8;
+#define SDR_PIPE_LAUNCH(C, N) hipLaunchKernelGGL((k_frontend_pipe<C, N>), pgrid, block, g.lds, h->stream, P, h->ktaps, g.pipe_tpw)
+        if (cu8 && g.pipe_nch == 8) SDR_PIPE_LAUNCH(true, 8);
+        else if (cu8 && g.pipe_nch == 16) SDR_PIPE_LAUNCH(true, 16);
+        else if (cu8) SDR_PIPE_LAUNCH(true, 32);
+        else if (g.pipe_nch == 8) SDR_PIPE_LAUNCH(false, 8);
+        else if (g.pipe_nch == 16) SDR_PIPE_LAUNCH(false, 16);
+        else SDR_PIPE_LAUNCH(false, 32);
+#undef SDR_PIPE_LAUNCH
+    } else if (h->in_fmt == SDR_IN_CU8) {
         if (g.use_lds)
             hipLaunchKernelGGL((k_frontend<true, true>), grid, block, g.lds, h->stream, P, h->ktaps);
         else
@@ -960,6 +973,31 @@ static void fill_geom(const sdr_handle* h, long long nout, long long in0, long l
         g.tile_out = g.T - q;
     }
     g.tiles = (int)((nout + g.tile_out - 1) / g.tile_out);
+    g.pipe_nch = g.pipe_tpw = 0;
+    if (!g.mfma && (h->pipe_mode >= 2 || (h->pipe_mode == 1 && h->in_fmt == SDR_IN_CU8))) {
+        // k_frontend_pipe: float tile only (cu8 needs no raw area), so the tile size is chosen
+        // as for complex64 input; chunks per lane must fit one of the instantiations
+        const int D = h->cfg.decim, nt = h->ntaps, spc = h->in_fmt == SDR_IN_CU8 ? 8 : 2;
+        for (int T : {256, 128, 64}) {
+            const long long count = (long long)(T - 1) * D + nt;
+            const size_t lds = (size_t)(count + 2 * spc) * sizeof(float2);
+            if (lds > 52 * 1024) continue;
+            const long long per = ((count + 2 * spc - 2) / spc + T - 1) / T;
+            const int nch = per <= 8 ? 8 : (per <= 16 ? 16 : (per <= 32 ? 32 : 0));
+            if (!nch) continue;
+            const int tile_out = T - q;
+            const int tiles = (int)((nout + tile_out - 1) / tile_out);
+            if (tiles < 2) break;
+            g.T = T;
+            g.lds = lds;
+            g.use_lds = true;
+            g.tile_out = tile_out;
+            g.tiles = tiles;
+            g.pipe_nch = nch;
+            g.pipe_tpw = h->pipe_tpw < tiles ? h->pipe_tpw : tiles;
+            break;
+        }
+    }
 }
 
 // geometry of k_demod_slice on the gated stream (one item per thread)

@@ -16,7 +16,7 @@ def main(fetch_csv, write_csv, out_json):
     f, w = agg(fetch_csv), agg(write_csv)
     n = 1250 * (1 << 18)
     want = [("k_frontend<true, false>", "k_frontend<true, false> fc32", 8.02 * n, "ook_batch_ts33c_xlating captures_per_gpu=1250"),
-            ("k_frontend<true, true>", "k_frontend<true, true> cu8", 2.02 * n, "ook_batch_cu8 captures_per_gpu=1250"),
+            ("k_frontend_pipe<true, 8>", "k_frontend_pipe<true, 8> cu8", 2.02 * n, "ook_batch_cu8 captures_per_gpu=1250"),
             ("k_pfb<8>", "k_pfb<8>", (8 + 1 / 16) * (1 << 26), "wideband_pfb64 samples=2^26")]
     out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE --kernel-trace (separate passes), python3 bench.py "
                      "--steps 3 --warmup 1 --no-cpu-baseline; per-launch means",
