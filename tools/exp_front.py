@@ -15,5 +15,5 @@ c.profile_enable(True)
 for _ in range(60):
     c.batch_process(iq)
 f, b = c.profile_read()
-ms = np.mean(f[10:])
+ms = np.mean(f[10:]); print("back %.4f ms" % np.mean(b[10:]))
 print(fmt, "PIPE=%s TPW=%s" % (os.environ.get("SDR_PIPE"), os.environ.get("SDR_TPW")), "SDR_DBG=%s front %.4f ms  %.0f GB/s" % (os.environ.get("SDR_DBG", "0"), ms, 8.02 * ncap * bench.N_PER_CAPTURE / ms / 1e6))
