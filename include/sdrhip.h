@@ -63,7 +63,9 @@ enum {
     SDR_DEC_BERNER = 5, /* ref: berner/sniff.py:21-44 */
     SDR_DEC_MUMBI = 6,  /* ref: mumbi/sniff.py:26-65 */
     SDR_DEC_KWMOBILE = 7, /* ref: kwmobile/decoder.py:95-135 (Nexus-type PPM, 36 bits) */
-    SDR_DEC_BALDR = 8   /* ref: baldr/decoder.py:87-142 (PPM, 37 bits, one decode per transmission) */
+    SDR_DEC_BALDR = 8,  /* ref: baldr/decoder.py:87-142 (PPM, 37 bits, one decode per transmission) */
+    SDR_DEC_VELUX = 9   /* ref: velux/decoder.py:30-101 (io-homecontrol: start of frame, UART framing, CRC-16/KERMIT);
+                           the sliced stream must hold one byte per symbol */
 };
 
 /* frame status (the reference reports these as debug strings) */
@@ -77,7 +79,8 @@ enum {
     SDR_FRAME_CHECKSUM = 6,       /* somfy checksum != 0 */
     SDR_FRAME_EXC_RESHAPE = 16,   /* reference raises ValueError (odd sync count, TFA/stream_decoder.py:137) */
     SDR_FRAME_EXC_INDEX = 17,     /* reference raises IndexError (no data start, TFA/stream_decoder.py:143) */
-    SDR_FRAME_EXC_NAN = 18        /* reference raises ValueError int(NaN) (TFA/stream_decoder.py:138) */
+    SDR_FRAME_EXC_NAN = 18,       /* reference raises ValueError int(NaN) (TFA/stream_decoder.py:138) */
+    SDR_FRAME_EXC_SHORT = 19      /* reference raises (bitstring unpack: fewer bits than the packet needs, velux/decoder.py:55,63,89) */
 };
 
 /* One flowgraph's parameters.  Field names follow the GRC block parameters.
@@ -112,7 +115,10 @@ typedef struct sdr_frame {
     uint8_t bytes[16]; /* packet (TS33C 10, TFA 11, somfy 7 de-obfuscated, berner 4, mumbi 5, kwmobile 5, baldr 5) */
     uint8_t raw[8];    /* somfy: the 7 on-air (obfuscated) bytes */
     int32_t v[4];      /* TS33C: channel, rolling code, battery_ok, humidity | TFA: id, humidity, battery_ok, 0 | somfy: control, rolling code, address, clock
-                          | kwmobile: sensor_id, humidity, battery_ok, channel | baldr: sensor_id, humidity, txMode, channel */
+                          | kwmobile: sensor_id, humidity, battery_ok, channel | baldr: sensor_id, humidity, txMode, channel
+                          | velux: the packet (nbytes <= 36: ff 33, control1, message, crc16 LE) runs from bytes[0] on
+                            through raw and v (40 contiguous bytes); pad_ = control1, temp_tenths = counter,
+                            lim[0] = frame start (symbol index), lim[1] = message length */
     int32_t temp_tenths; /* TS33C/TFA/kwmobile/baldr temperature in 0.1 C */
     int32_t pad_;
     double lim[2];     /* TS33C: pulse/gap short limit (us) | TFA: symbol_length (us), 0 */

@@ -582,6 +582,66 @@ def baldr_decode(symbols):
                 sensor_id=int(((frame[0] & 0x0f) << 4) | (frame[1] >> 4)))
 
 
+# --------------------------------------------------------------------- velux
+VELUX_SOF = [0, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 1, 1, 0, 0, 1, 1, 0, 0, 1]  # "0 11111111 1 0 11001100 1" (velux/decoder.py:31)
+
+
+def crc16_kermit(data):
+    """Crc16.KERMIT of the `crc` package (velux/decoder.py:64): poly 0x1021
+    reflected (0x8408), init 0, no final xor."""
+    crc = 0
+    for b in bytearray(data):
+        crc ^= b
+        for _ in range(8):
+            crc = (crc >> 1) ^ 0x8408 if crc & 1 else crc >> 1
+    return crc
+
+
+def velux_decode(bits):
+    """velux/decoder.py:30-101 on a list of 0/1 symbols, with plain lists in
+    place of bitstring (same slice-deletion semantics).  Returns None when no
+    start of frame is found (the script exits), else a dict; `error` is set
+    where bitstring's unpack would raise (too few bits)."""
+    bits = [int(b) for b in bits]
+    n, m = len(bits), len(VELUX_SOF)
+    start = -1
+    for i in range(0, n - m + 1):
+        if bits[i:i + m] == VELUX_SOF:
+            start = i
+            break
+    if start < 0:
+        return None
+    frame = bits[start:]
+    del frame[0:len(frame):10]      # start bits (:43)
+    del frame[8:len(frame):9]       # stop bits (:45)
+    for i in range(0, len(frame) - 8, 8):   # LSB first -> reverse every byte but the last group (:48-49)
+        frame[i:i + 8] = frame[i:i + 8][::-1]
+    out = dict(frame_start=start, error=None)
+    if len(frame) < 24:
+        out["error"] = "short"
+        return out
+    control1 = int("".join(str(b) for b in frame[16:24]), 2)
+    ml = control1 & 0x1F
+    packet = frame[:(3 + ml + 2) * 8]
+    pb = packet + [0] * (-len(packet) % 8)
+    data = bytes(bytearray(int("".join(str(b) for b in pb[i:i + 8]), 2) for i in range(0, len(pb), 8)))
+    out.update(packet=data, control1=control1 & ~0x1F & 0xFF, message_length=ml)
+    if len(packet) < (3 + ml + 2) * 8:
+        out["error"] = "short"
+        return out
+    crc16 = data[3 + ml] | (data[3 + ml + 1] << 8)
+    crc_calc = crc16_kermit(data[2:3 + ml])
+    out.update(crc16=crc16, crc_ok=crc_calc == crc16)
+    msg = data[3:3 + ml]
+    if ml < 16:
+        out["error"] = "short message"   # unpack("... bytes:{ml-16} ...") raises
+        return out
+    out.update(control2=msg[0], destination=int.from_bytes(msg[1:4], "big"), source=int.from_bytes(msg[4:7], "big"),
+               command=msg[7], payload=msg[8:ml - 8], counter=int.from_bytes(msg[ml - 8:ml - 6], "big"),
+               mac=int.from_bytes(msg[ml - 6:ml], "big"))
+    return out
+
+
 def edges_to_events(bits, sample_rate, watchdog_us=None, start_level=0):
     """Turn a sliced 0/1 stream into the (level, tick) events a pigpio
     EITHER_EDGE callback with an optional watchdog would deliver: tick = sample

@@ -13,7 +13,7 @@ SDR_OK, SDR_E_ARG, SDR_E_HIP, SDR_E_CAPACITY, SDR_E_OVERFLOW, SDR_E_NODEVICE = 0
 WIN_HAMMING, WIN_HANN, WIN_BLACKMAN, WIN_RECTANGULAR, WIN_KAISER, WIN_BLACKMAN_HARRIS = range(6)
 DEMOD_NONE, DEMOD_MAG2, DEMOD_QUAD = 0, 1, 2
 IN_FC32, IN_CU8 = 0, 1
-DEC_NONE, DEC_TS33C, DEC_TFA, DEC_TFA_GRC, DEC_SOMFY, DEC_BERNER, DEC_MUMBI, DEC_KWMOBILE, DEC_BALDR = range(9)
+DEC_NONE, DEC_TS33C, DEC_TFA, DEC_TFA_GRC, DEC_SOMFY, DEC_BERNER, DEC_MUMBI, DEC_KWMOBILE, DEC_BALDR, DEC_VELUX = range(10)
 
 FRAME_OK = 0
 FRAME_BAD_LENGTH = 1
@@ -25,6 +25,7 @@ FRAME_CHECKSUM = 6
 FRAME_EXC_RESHAPE = 16
 FRAME_EXC_INDEX = 17
 FRAME_EXC_NAN = 18
+FRAME_EXC_SHORT = 19
 
 #: the reference's debug strings for each status (TS33C/stream_decoder.py:198-202,
 #: TFA/stream_decoder.py:197-199, TFA/analyzer2.grc:960)
@@ -83,6 +84,8 @@ class Frame(C.Structure):
     ]
 
     def packet(self):
+        if self.nbytes > 16:   # velux: the packet runs on through raw and v (40 contiguous bytes)
+            return C.string_at(C.addressof(self) + Frame.bytes.offset, min(self.nbytes, 40))
         return bytes(bytearray(self.bytes[: self.nbytes]))
 
 

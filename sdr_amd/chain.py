@@ -12,7 +12,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import (DEC_BALDR, DEC_BERNER, DEC_KWMOBILE, DEC_MUMBI, DEC_NONE, DEC_SOMFY, DEC_TFA, DEC_TFA_GRC, DEC_TS33C,  # noqa: F401
+from ._lib import (DEC_BALDR, DEC_BERNER, DEC_KWMOBILE, DEC_MUMBI, DEC_VELUX, DEC_NONE, DEC_SOMFY, DEC_TFA, DEC_TFA_GRC, DEC_TS33C,  # noqa: F401
                    DEMOD_MAG2, DEMOD_NONE, DEMOD_QUAD, WIN_BLACKMAN, WIN_HAMMING, WIN_KAISER)
 
 

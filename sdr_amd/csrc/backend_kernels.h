@@ -9,6 +9,7 @@
 // not bandwidth-bound; its traffic (1/(D*keep_n) B per input sample) is noise
 // beside the front end's 8 B.
 #pragma once
+#include <stddef.h>
 #include "sdr_common.h"
 
 #define BK_THREADS 256
@@ -610,6 +611,88 @@ SDR_HD inline void rule_baldr(const EdgeCtx& e, const BackParams& P, DecState* s
     }
     long long end_tick = (e.nb * 1000000LL) / e.rate_hz;
     if (end_tick - prev_tick > wd) watchdog(e.nb);
+}
+
+// velux/decoder.py:30-101 (io-homecontrol): the sliced stream is one byte per symbol.
+// Find the start of frame "0 11111111 1 0 11001100 1", drop the UART start/stop bits of
+// every 10-bit group, bytes LSB first (the script reverses every byte except the last
+// group it holds), message length = control1 & 0x1f, CRC-16/KERMIT over bytes
+// [2, 3+len) against the little-endian word behind them.  One frame per call (the
+// script decodes the first start of frame only).  The packet (<= 36 bytes) is stored
+// from sdr_frame.bytes on through .raw and .v (40 contiguous bytes).
+SDR_HD inline void rule_velux(const EdgeCtx& e, const BackParams& P, DecState* st, int cap)
+{
+    static_assert(offsetof(sdr_frame, raw) == offsetof(sdr_frame, bytes) + 16 &&
+                      offsetof(sdr_frame, v) == offsetof(sdr_frame, bytes) + 24,
+                  "velux packet spans bytes/raw/v");
+    const unsigned int SOF = 0x7FD99u;   // 0 11111111 1 0 11001100 1
+    long long k = 0;                     // run index of bit i
+    int level = e.first_level;
+    unsigned int win = 0;
+    long long start = -1;
+    long long i = 0;
+    for (; i < e.nb; ++i) {
+        while (k + 1 < e.R && i >= e.pos[k + 1]) {
+            ++k;
+            level ^= 1;
+        }
+        win = ((win << 1) | (unsigned)level) & 0xFFFFFu;
+        if (i >= 19 && win == SOF) {
+            start = i - 19;
+            break;
+        }
+    }
+    if (start < 0) return;
+    sdr_frame* f = next_frame(P, st, cap, e.nb);
+    if (!f) return;
+    // rewind the run pointer to `start`
+    k = 0;
+    level = e.first_level;
+    const long long nrem = e.nb - start;
+    const long long q = nrem / 10, r = nrem % 10;
+    const long long L = 8 * q + (r > 0 ? r - 1 : 0);   // data bits the script keeps
+    unsigned char* pk = f->bytes;                        // 40 contiguous bytes
+    for (int b = 0; b < 40; ++b) pk[b] = 0;
+    for (long long j = 0; j < nrem && j < 400; ++j) {
+        const long long ii = start + j;
+        while (k + 1 < e.R && ii >= e.pos[k + 1]) {
+            ++k;
+            level ^= 1;
+        }
+        const int t = (int)(j % 10) - 1;
+        if (t < 0 || t > 7) continue;
+        const long long by = j / 10;
+        const bool reversed = 8 * by < L - 8;
+        if (level) pk[by] |= (unsigned char)(reversed ? (1u << t) : (0x80u >> t));
+    }
+    f->nbits = (int)(L > 0x7fffffff ? 0x7fffffff : L);
+    f->lim[0] = (double)start;
+    if (L < 24) {
+        f->nbytes = (int)((L + 7) / 8);
+        f->status = SDR_FRAME_EXC_SHORT;
+        return;
+    }
+    const int control1 = pk[2], ml = control1 & 0x1f, plen = 3 + ml + 2;
+    f->pad_ = control1;
+    f->lim[1] = (double)ml;
+    if (L < 8LL * plen) {
+        const long long have = (L + 7) / 8;
+        f->nbytes = (int)(have < 40 ? have : 40);
+        f->status = SDR_FRAME_EXC_SHORT;
+        return;
+    }
+    for (int b = plen; b < 40; ++b) pk[b] = 0;   // strip trailing noise
+    // a partial trailing bit group never reaches into the packet here (L >= 8*plen), but the
+    // un-reversed last group can: the script's quirk is kept by `reversed` above
+    unsigned int crc = 0;
+    for (int b = 2; b < 3 + ml; ++b) {
+        crc ^= pk[b];
+        for (int s2 = 0; s2 < 8; ++s2) crc = (crc & 1u) ? ((crc >> 1) ^ 0x8408u) : (crc >> 1);
+    }
+    const unsigned int got = (unsigned)pk[3 + ml] | ((unsigned)pk[3 + ml + 1] << 8);
+    f->nbytes = plen;
+    f->temp_tenths = ml >= 16 ? (((int)pk[3 + ml - 8] << 8) | pk[3 + ml - 7]) : 0;   // counter
+    f->status = (crc == got) ? (ml >= 16 ? SDR_FRAME_OK : SDR_FRAME_EXC_SHORT) : SDR_FRAME_CRC;
 }
 
 // ---- the stream decoder front end (TS33C/stream_decoder.py:39-110,204-217) ----

@@ -227,6 +227,8 @@ __global__ void __launch_bounds__(BK_THREADS) k_backend(BackParams P)
             rule_kwmobile(e, P, &ls, cap, s_bits);
         else if (P.decoder == SDR_DEC_BALDR)
             rule_baldr(e, P, &ls, cap, s_bits);
+        else if (P.decoder == SDR_DEC_VELUX)
+            rule_velux(e, P, &ls, cap);
     }
     if (tid == 0) *st = ls;
 }

@@ -142,7 +142,7 @@ static int pfb_batch(sdr_handle* h, const void* iq, size_t n, size_t stride, int
 // from a fresh decoder object, as in sdr_batch_process); the frame table is replaced.
 extern "C" int sdr_redecode(sdr_handle* h, int decoder, double decoder_rate)
 {
-    if (!h || decoder <= SDR_DEC_NONE || decoder > SDR_DEC_BALDR) return fail(h, SDR_E_ARG, "sdr_redecode: bad decoder");
+    if (!h || decoder <= SDR_DEC_NONE || decoder > SDR_DEC_VELUX) return fail(h, SDR_E_ARG, "sdr_redecode: bad decoder");
     if (h->cfg.demod == SDR_DEMOD_NONE || h->skip_slice) return fail(h, SDR_E_ARG, "sdr_redecode: the chain has no sliced stream");
     if (h->last_ncap < 1) return fail(h, SDR_E_ARG, "sdr_redecode: no batch processed yet");
     if (h->last_bits_off != 0 || h->raw_n != 0) return fail(h, SDR_E_ARG, "sdr_redecode: only after sdr_batch_process");

@@ -457,7 +457,7 @@ extern "C" int sdr_create(const sdr_chain_cfg* cfg, sdr_handle** out)
     *out = nullptr;
     if (cfg->decim < 1 || cfg->keep_n < 1 || cfg->max_batch < 1 || cfg->max_samples < 1 ||
         !(cfg->sample_rate > 0) || cfg->demod < SDR_DEMOD_NONE || cfg->demod > SDR_DEMOD_QUAD ||
-        cfg->decoder < SDR_DEC_NONE || cfg->decoder > SDR_DEC_BALDR || cfg->post_ntaps < 0)
+        cfg->decoder < SDR_DEC_NONE || cfg->decoder > SDR_DEC_VELUX || cfg->post_ntaps < 0)
         return fail(nullptr, SDR_E_ARG, "sdr_create: bad configuration");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)

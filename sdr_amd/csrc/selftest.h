@@ -93,6 +93,7 @@ extern "C" SDR_API int sdr_selftest_dec_work(void* p, const int8_t* bits, size_t
             if (d->decoder == SDR_DEC_MUMBI) rule_mumbi(e, P, &d->st, 0, sb.data());
             if (d->decoder == SDR_DEC_KWMOBILE) rule_kwmobile(e, P, &d->st, 0, sb.data());
             if (d->decoder == SDR_DEC_BALDR) rule_baldr(e, P, &d->st, 0, sb.data());
+            if (d->decoder == SDR_DEC_VELUX) rule_velux(e, P, &d->st, 0);
         }
         *nframes = (size_t)d->st.n_frames;
         for (size_t i = 0; i < *nframes && i < cap && out; ++i) out[i] = d->frames[i];

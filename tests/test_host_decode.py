@@ -315,3 +315,34 @@ def _jitter_env(rng, env):
         start = q
     out[start:] = lvl
     return out
+
+
+def test_velux_host_vs_oracle(L, kat):
+    """rule_velux (host-compiled) against the oracle restatement: the reference's two captures,
+    truncations (the script's unpack errors), bit flips (CRC) and random prefixes."""
+    rng = np.random.default_rng(77)
+    base = kat["velux_active"]["bits"]
+    cases = [base, kat["velux_commented"]["bits"], base[:150], base[:380], base[:372], base[:371], base[:130]]
+    for _ in range(6):
+        b = list(rng.integers(0, 2, int(rng.integers(0, 40)))) + list(base[80:])
+        if rng.random() < 0.5:
+            b[int(rng.integers(130, len(b)))] ^= 1
+        cases.append(b)
+    for bits in cases:
+        o = dec.velux_decode(bits)
+        g = HostDec(L, _lib.DEC_VELUX, 1)
+        g.work(np.asarray(bits, np.int8))
+        if o is None:
+            assert g.frames == []
+        else:
+            assert len(g.frames) == 1
+            f = g.frames[0]
+            assert int(f.lim[0]) == o["frame_start"]
+            if o["error"] == "short":
+                assert f.status == _lib.FRAME_EXC_SHORT
+            else:
+                assert f.packet() == o["packet"]
+                assert (f.status == _lib.FRAME_OK) == (o["crc_ok"] and o["error"] is None)
+                if o["error"] is None:
+                    assert f.temp_tenths == o["counter"] and int(f.lim[1]) == o["message_length"]
+        g.close()

@@ -256,3 +256,18 @@ def test_baldr_rule_round_trip():
     for lvl, tick in dec.edges_to_events(env, 1e6, watchdog_us=18000):
         s.cbf(lvl, tick)
     assert [f["frame"] for f in s.frames] == [d["frame"]]  # one decode per transmission
+
+
+def test_velux_reference_arrays(kat):
+    """velux/decoder.py:22-28: the active symbol array decodes to a packet whose CRC-16/KERMIT
+    verifies, with the message / counter / MAC the script's docstring quotes; the commented-out
+    capture has a failing CRC."""
+    k = kat["velux_active"]
+    d = dec.velux_decode(k["bits"])
+    assert d["packet"].hex() == k["packet_hex"] and d["crc_ok"] is True and d["error"] is None
+    assert d["payload"].hex() == k["message_hex"] and d["counter"] == k["counter"]
+    assert "%012x" % d["mac"] == k["mac_hex"] and d["packet"][2:3].hex() == k["msg_type_hex"]
+    assert dec.crc16_kermit(b"123456789") == 0x2189   # CRC-16/KERMIT check value
+    d2 = dec.velux_decode(kat["velux_commented"]["bits"])
+    assert d2["crc_ok"] is False and d2["counter"] == kat["velux_commented"]["counter"]
+    assert dec.velux_decode([0, 1] * 100) is None
