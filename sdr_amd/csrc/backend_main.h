@@ -10,7 +10,7 @@
 
 #define BK_BYTES_LDS 8192
 
-__global__ void __launch_bounds__(BK_THREADS) k_backend(BackParams P)
+__global__ void __launch_bounds__(BK_THREADS, 6) k_backend(BackParams P)
 {
     __shared__ __align__(16) unsigned char s_A[SDR_CUR_CAP * 8];
     __shared__ __align__(16) unsigned char s_B[SDR_CUR_CAP * 8];
@@ -31,6 +31,9 @@ __global__ void __launch_bounds__(BK_THREADS) k_backend(BackParams P)
     int* s_last = s_has + BK_THREADS;
 
     const int cap = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+#ifdef SDR_BK_TIMING
+    long long tk0 = __builtin_readcyclecounter(), tk1 = 0, tk2 = 0, tk3 = 0;
+#endif
     int8_t* bits = P.bits + (long long)cap * P.bits_stride;
     DecState* st = P.st + cap;
     // behind a gating squelch every capture of a batch has its own length
@@ -125,6 +128,9 @@ __global__ void __launch_bounds__(BK_THREADS) k_backend(BackParams P)
     }
     if (!run_decoder || P.decoder == SDR_DEC_NONE) return;
     __syncthreads();
+#ifdef SDR_BK_TIMING
+    tk1 = __builtin_readcyclecounter();
+#endif
 
     // ---- phase 1: run-length ------------------------------------------------
     int32_t* pos = P.runs + (long long)cap * (P.runs_cap + 2);
@@ -201,6 +207,9 @@ __global__ void __launch_bounds__(BK_THREADS) k_backend(BackParams P)
         for (int k = tid; k < npend && k < SDR_CUR_CAP; k += BK_THREADS) s_cur[k] = gcur[k];
     }
     __syncthreads();
+#ifdef SDR_BK_TIMING
+    tk2 = __builtin_readcyclecounter();
+#endif
     if (tid >= 64) return;
 
     // ---- phase 2: decode on wavefront 0 ----------------------------------------
@@ -231,4 +240,8 @@ __global__ void __launch_bounds__(BK_THREADS) k_backend(BackParams P)
             rule_velux(e, P, &ls, cap);
     }
     if (tid == 0) *st = ls;
+#ifdef SDR_BK_TIMING
+    tk3 = __builtin_readcyclecounter();
+    if (tid == 0 && (cap == 0 || cap == 700)) printf("cap %d: phase0 %lld phase1 %lld phase2 %lld cycles (R=%lld)\n", cap, tk1 - tk0, tk2 - tk1, tk3 - tk2, R);
+#endif
 }

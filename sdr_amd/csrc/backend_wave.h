@@ -28,21 +28,69 @@ struct WaveLds {
     unsigned char* par;     // [256] parity bits
 };
 
+__device__ __forceinline__ double readlane_f64(double x, int l)
+{
+    const long long b = __builtin_bit_cast(long long, x);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, l);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), l);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)lo);
+}
+
 // dst[rank] = value for every valid element; returns the number of valid ones.
+// Candidates are held one per lane and broadcast with v_readlane (uniform lane index):
+// no LDS round trip inside the O(n^2/64) loop -- the first version read every
+// candidate from LDS and made the sort ~14 us of single-wave latency per call.
 template <class V, class OK>
 __device__ inline int wave_rank_sort(V val, OK ok, int n, double* dst)
 {
     const int lane = threadIdx.x & 63;
+    if (n <= 128) {
+        // Bitonic network over 128 slots, two per lane (element e = 64 h + lane), invalid slots
+        // hold +inf and sort to the end: 28 compare-exchange rounds of v_min/v_max_f64 instead
+        // of an O(n^2/64) rank count (measured: 12 us -> ~1 us of single-wave latency for the 73
+        // pulses of a TS33C packet).  The sorted array is the same whatever the order of ties.
+        const double inf = __builtin_inf();
+        const bool m0 = lane < n && ok(lane), m1 = lane + 64 < n && ok(lane + 64);
+        double a0 = m0 ? val(lane) : inf, a1 = m1 ? val(lane + 64) : inf;
+        const int total = __builtin_popcountll(__ballot(m0)) + __builtin_popcountll(__ballot(m1));
+        for (int k = 2; k <= 128; k <<= 1) {
+            for (int j = k >> 1; j >= 1; j >>= 1) {
+                if (j == 64) {   // partner = the lane's other slot; k == 128: ascending
+                    const double lo = fmin(a0, a1), hi = fmax(a0, a1);
+                    a0 = lo;
+                    a1 = hi;
+                } else {
+                    const double b0 = __shfl_xor(a0, j), b1 = __shfl_xor(a1, j);
+                    const bool lower = (lane & j) == 0;
+                    // slot index e = lane (h = 0) or 64 + lane (h = 1): ascending iff (e & k) == 0
+                    const bool asc0 = (lane & k) == 0, asc1 = ((64 + lane) & k) == 0;
+                    a0 = (lower == asc0) ? fmin(a0, b0) : fmax(a0, b0);
+                    a1 = (lower == asc1) ? fmin(a1, b1) : fmax(a1, b1);
+                }
+            }
+        }
+        if (lane < total) dst[lane] = a0;
+        if (lane + 64 < total) dst[lane + 64] = a1;
+        wave_sync();
+        return total;
+    }
     int total = 0;
     for (int base = 0; base < n; base += 64) {
         const int i = base + lane;
         const bool mine = i < n && ok(i);
         const double v = mine ? val(i) : 0.0;
         int rank = 0;
-        for (int j = 0; j < n; ++j) {
-            const double u = val(j);
-            const bool vj = ok(j);
-            rank += (vj && (u < v || (u == v && j < i))) ? 1 : 0;
+        for (int bj = 0; bj < n; bj += 64) {
+            const int jj = bj + lane;
+            const bool okj = jj < n && ok(jj);
+            const double ul = okj ? val(jj) : 0.0;
+            const unsigned long long okmask = __ballot(okj);
+            const int nt = okmask ? 64 - __builtin_clzll(okmask) : 0;   // uniform: nothing valid beyond
+            for (int t = 0; t < nt; ++t) {
+                const double u = readlane_f64(ul, t);
+                const int jx = bj + t;
+                rank += (((okmask >> t) & 1ull) && (u < v || (u == v && jx < i))) ? 1 : 0;
+            }
         }
         if (mine) dst[rank] = v;
         total += __builtin_popcountll(__ballot(mine));
@@ -60,9 +108,18 @@ __device__ inline void wave_decode_ts33c(const WaveLds& L, int n, double reset_l
     const int np_ = (n + 1) / 2, ng = n / 2;
     auto pulse = [&](int j) { return cur[2 * j]; };
     auto all_ok = [&](int) { return true; };
+#ifdef SDR_BK_TIMING
+    long long q0 = __builtin_readcyclecounter();
+#endif
     wave_rank_sort(pulse, all_ok, np_, L.scratch);
+#ifdef SDR_BK_TIMING
+    long long q1 = __builtin_readcyclecounter();
+#endif
     const double plim = hist_auto_mid_edge(L.scratch, np_, P.pow_m13, P.log2n);
     wave_sync();
+#ifdef SDR_BK_TIMING
+    long long q2 = __builtin_readcyclecounter();
+#endif
     auto gap = [&](int j) { return cur[2 * j + 1]; };
     auto gap_ok = [&](int j) {
         double g = cur[2 * j + 1];
@@ -133,6 +190,10 @@ __device__ inline void wave_decode_ts33c(const WaveLds& L, int n, double reset_l
         else
             status = SDR_FRAME_OK;
     }
+#ifdef SDR_BK_TIMING
+    long long q3 = __builtin_readcyclecounter();
+    if (lane == 0 && blockIdx.x == 0) printf("  ts33c n=%d: sort %lld hist %lld rest(sort2+hist2+bits) %lld\n", n, q1 - q0, q2 - q1, q3 - q2);
+#endif
     if (lane == 0 && f) {
         f->lim[0] = plim;
         f->lim[1] = glim;
