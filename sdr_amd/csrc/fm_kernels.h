@@ -92,7 +92,7 @@ __global__ void __launch_bounds__(DEEMPH_THREADS) k_deemph(const float* __restri
 // thread that starts `warm` samples early from y = 0 reaches the true state to
 // below double rounding (p1^warm < 2^-60) before its own chunk begins.  One
 // thread = DEEMPH_CHUNK outputs; any number of workgroups.
-#define DEEMPH_CHUNK 64
+#define DEEMPH_CHUNK 16
 __global__ void __launch_bounds__(256) k_deemph_warm(const float* __restrict__ x, long long n, double b0, double p1,
                                                      int warm, float* __restrict__ y)
 {

@@ -1,0 +1,63 @@
+"""Build-time guard for a code-generation hazard measured on the GPU (DESIGN.md section 4,
+r01_i): if the compiler places `s_waitcnt vmcnt(0)` inside the staging loop, every 16-B
+direct-to-LDS DMA is waited for before the next one is issued and the front end runs 2.7x
+slower (0.46 -> 1.24 ms) with identical results -- no parity test can see it.  This test
+compiles the device code to assembly (no GPU needed) and checks that the innermost loop
+around every `global_load_lds_dwordx4` of the streaming kernels holds no vmcnt wait."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KERNELS = {
+    "_Z10k_frontendILb1ELb0EEv11FrontParams10FrontKTaps": "k_frontend<true,false>",
+    "_Z15k_frontend_mfma11FrontParams": "k_frontend_mfma",
+    "_Z5k_pfbILi8EEv9PfbParams": "k_pfb<8>",
+}
+
+
+@pytest.fixture(scope="module")
+def device_asm(tmp_path_factory):
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    out = tmp_path_factory.mktemp("asm") / "sdrhip.s"
+    src = os.path.join(ROOT, "sdr_amd", "csrc", "sdrhip.hip")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-S",
+                           "--cuda-device-only", "-o", str(out), src], cwd=os.path.dirname(src))
+    return open(str(out)).read()
+
+
+def _kernel_body(asm, sym):
+    i = asm.index(sym + ":")
+    return asm[i:asm.index(".end_amdhsa_kernel", i)].split("\n")
+
+
+def _innermost_loop(lines, at):
+    labels = {m.group(1): k for k, l in enumerate(lines) for m in [re.match(r"^(\.LBB\d+_\d+):", l)] if m}
+    best = None
+    for b in range(at + 1, len(lines)):
+        m = re.match(r"^\s+s_(?:c?branch\w*)\s+(\.LBB\d+_\d+)", lines[b])
+        if m and labels.get(m.group(1), 1 << 30) <= at:
+            best = (labels[m.group(1)], b)
+            break
+    return best
+
+
+@pytest.mark.parametrize("sym", sorted(KERNELS))
+def test_no_vmcnt_wait_inside_the_dma_loop(device_asm, sym):
+    lines = _kernel_body(device_asm, sym)
+    dma = [k for k, l in enumerate(lines) if "global_load_lds_dwordx4" in l]
+    assert dma, "%s no longer stages by LDS DMA" % KERNELS[sym]
+    for at in dma:
+        assert " nt" in lines[at], "staging DMA lost its non-temporal policy"
+        loop = _innermost_loop(lines, at)
+        assert loop is not None, "DMA is not inside a loop?"
+        body = lines[loop[0]:loop[1] + 1]
+        waits = [l.strip() for l in body if re.search(r"s_waitcnt.*vmcnt\(", l)]
+        assert not waits, "%s: the staging loop waits on its own DMA: %s" % (KERNELS[sym], waits)
+        others = [l.strip() for l in body if re.search(r"\b(global_load_dword|global_load_u|buffer_load|flat_load)", l)]
+        assert not others, "%s: other loads share the DMA loop: %s" % (KERNELS[sym], others)
