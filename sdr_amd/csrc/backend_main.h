@@ -24,7 +24,6 @@ __global__ void __launch_bounds__(BK_THREADS, 6) k_backend(BackParams P)
 
     double* s_cur = reinterpret_cast<double*>(s_A);
     double* s_scratch = reinterpret_cast<double*>(s_B);
-    int8_t* s_b = reinterpret_cast<int8_t*>(s_B);
     double* s_w = reinterpret_cast<double*>(s_C);
     long long* s_tick = reinterpret_cast<long long*>(s_C);
     int* s_has = reinterpret_cast<int*>(s_C);
@@ -134,14 +133,94 @@ __global__ void __launch_bounds__(BK_THREADS, 6) k_backend(BackParams P)
 
     // ---- phase 1: run-length ------------------------------------------------
     int32_t* pos = P.runs + (long long)cap * (P.runs_cap + 2);
-    const bool b_in_lds = nb <= BK_BYTES_LDS && ((reinterpret_cast<uintptr_t>(bits) & 15) == 0);
-    if (b_in_lds) {
-        // 16-B loads; the tail read stays inside the capture's 64-B padded row
-        for (long long i = (long long)tid * 16; i < nb; i += BK_THREADS * 16)
-            *reinterpret_cast<int4*>(s_b + i) = *reinterpret_cast<const int4*>(bits + i);
+    // Short rows (<= 8192 bytes, the batch case): every thread owns 32 bytes, held in
+    // registers as 8 dwords straight from global memory; edges come from word arithmetic
+    // (d = w ^ (w << 8 | previous byte); a byte of d is non-zero where the level changes)
+    // instead of a byte-at-a-time walk through LDS, and the run starts are kept in LDS too
+    // so that the widths do not wait on a global write/read round trip.
+    const bool fast = nb <= BK_BYTES_LDS && ((reinterpret_cast<uintptr_t>(bits) & 15) == 0) && (P.bits_stride & 31) == 0;
+    int32_t* s_pos = reinterpret_cast<int32_t*>(s_B);   // [2048], free until phase 2 needs its sort scratch
+    long long R = 0;
+    bool runs_overflow = false;
+    bool w_in_lds = false, pos_in_lds = false;
+    int first_level = 0, last_level = 0;
+    if (fast) {
+        const int j0 = tid * 32;
+        unsigned wd[8];
+        int valid = (int)nb - j0;
+        valid = valid < 0 ? 0 : (valid > 32 ? 32 : valid);
+        if (j0 < P.bits_stride && valid > 0) {
+            const uint4 a = *reinterpret_cast<const uint4*>(bits + j0), b = *reinterpret_cast<const uint4*>(bits + j0 + 16);
+            wd[0] = a.x; wd[1] = a.y; wd[2] = a.z; wd[3] = a.w;
+            wd[4] = b.x; wd[5] = b.y; wd[6] = b.z; wd[7] = b.w;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) wd[k] = 0;
+        }
+        unsigned prevb = (valid > 0) ? (j0 > 0 ? (unsigned)(unsigned char)bits[j0 - 1] : (wd[0] & 0xffu)) : 0u;
+        unsigned nz[8];
+        int cnt = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const unsigned d = wd[k] ^ ((wd[k] << 8) | prevb);
+            unsigned m = (((d & 0x7f7f7f7fu) + 0x7f7f7f7fu) | d) & 0x80808080u;   // bit 7 of every non-zero byte
+            const int left = valid - 4 * k;                                      // bytes of this word inside the row
+            if (left <= 0)
+                m = 0;
+            else if (left < 4)
+                m &= (1u << (8 * left)) - 1u;
+            nz[k] = m;
+            cnt += __builtin_popcount(m);
+            prevb = wd[k] >> 24;
+        }
+        int incl = cnt;
+        for (int off = 1; off < 64; off <<= 1) {
+            int t = __shfl_up(incl, off);
+            if (lane >= off) incl += t;
+        }
+        if (lane == 63) s_wtot[wv] = incl;
         __syncthreads();
-    }
-    const int8_t* bb = b_in_lds ? s_b : bits;
+        int wbase = 0, total = 0;
+        for (int w = 0; w < 4; ++w) {
+            if (w < wv) wbase += s_wtot[w];
+            total += s_wtot[w];
+        }
+        R = nb > 0 ? (long long)total + 1 : 0;
+        if (R > P.runs_cap) {
+            runs_overflow = true;
+            R = P.runs_cap;
+        }
+        w_in_lds = R <= SDR_CUR_CAP;
+        pos_in_lds = R + 1 <= 2048;
+        first_level = nb > 0 ? (bits[0] != 0) : 0;
+        last_level = nb > 0 ? (bits[nb - 1] != 0) : 0;
+        if (tid == 0) {
+            pos[0] = 0;
+            s_pos[0] = 0;
+        }
+        long long w = 1 + wbase + incl - cnt;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            unsigned m = nz[k];
+            while (m) {
+                const int by = __builtin_ctz(m) >> 3;
+                const int32_t at = j0 + 4 * k + by;
+                if (w < R) {
+                    pos[w] = at;
+                    if (w < 2048) s_pos[w] = at;
+                }
+                ++w;
+                m &= m - 1;
+            }
+        }
+        if (tid == 0) {
+            pos[R] = (int32_t)nb;
+            if (R < 2048) s_pos[R] = (int32_t)nb;
+        }
+        __syncthreads();
+    } else {
+    const bool b_in_lds = false;
+    const int8_t* bb = bits;
     const long long per = (nb + BK_THREADS - 1) / BK_THREADS;
     const long long j0 = (long long)tid * per, j1 = (j0 + per < nb) ? j0 + per : nb;
     int cnt = 0;
@@ -166,15 +245,15 @@ __global__ void __launch_bounds__(BK_THREADS, 6) k_backend(BackParams P)
         if (w < wv) wbase += s_wtot[w];
         total += s_wtot[w];
     }
-    long long R = (long long)total + 1;
+    R = (long long)total + 1;
     if (nb == 0) R = 0;
-    bool runs_overflow = false;
     if (R > P.runs_cap) {
         runs_overflow = true;
         R = P.runs_cap;
     }
-    const bool w_in_lds = R <= SDR_CUR_CAP;
-    const int first_level = nb > 0 ? (bb[0] != 0) : 0, last_level = nb > 0 ? (bb[nb - 1] != 0) : 0;
+    w_in_lds = R <= SDR_CUR_CAP;
+    first_level = nb > 0 ? (bb[0] != 0) : 0;
+    last_level = nb > 0 ? (bb[nb - 1] != 0) : 0;
     if (tid == 0) pos[0] = 0;
     {
         long long w = 1 + wbase + incl - cnt;
@@ -190,16 +269,19 @@ __global__ void __launch_bounds__(BK_THREADS, 6) k_backend(BackParams P)
     }
     if (tid == 0) pos[R] = (int32_t)nb;
     __syncthreads();  // pos[] (global) written by this block is read back below
+    (void)b_in_lds;
+    }
     if (nb == 0) return;
 
     // run widths (stream decoders) or edge ticks (callback rules) into LDS
     const bool stream_dec = P.decoder <= SDR_DEC_TFA_GRC;
+    const int32_t* rpos = pos_in_lds ? s_pos : pos;
     if (w_in_lds) {
         if (stream_dec)
-            for (long long k = tid; k < R; k += BK_THREADS) s_w[k] = run_width(pos, k, P.dec_rate);
+            for (long long k = tid; k < R; k += BK_THREADS) s_w[k] = run_width(rpos, k, P.dec_rate);
         else
             for (long long k = tid; k < R; k += BK_THREADS)
-                s_tick[k] = ((long long)pos[k] * 1000000LL) / (long long)P.dec_rate;
+                s_tick[k] = ((long long)rpos[k] * 1000000LL) / (long long)P.dec_rate;
     }
     double* gcur = P.cur + (long long)cap * SDR_CUR_CAP;
     if (stream_dec) {

@@ -4,8 +4,8 @@
 // [GR-ext], computed as 64 polyphase branch sums + a 64-point DFT, with mag^2 /
 // gain / threshold_ff / slicer / keep_one_in_n fused behind it.  HBM-bound: 8 B
 // read per input sample, 1/keep_n B written (all 64 channels together produce
-// one output per input sample).  No MFMA: the DFT is 6 butterfly stages across
-// the lanes of a wavefront, not a dense contraction.
+// one output per input sample).  No MFMA: the 64-point DFT is a 4 x 16 FFT in
+// registers (30 flop per input sample), not a dense contraction.
 //
 // Numeric contract = oracle/dsp_oracle.c orc_pfb_channelize, op for op.
 //
