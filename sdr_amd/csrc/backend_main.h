@@ -307,7 +307,7 @@ __global__ void __launch_bounds__(BK_THREADS, 6) k_backend(BackParams P)
                                &ls);
         for (int k = tid; k < ls.n_cur; k += 64) gcur[k] = s_cur[k];
     } else if (tid == 0) {
-        EdgeCtx e{pos, w_in_lds ? s_tick : nullptr, R, nb, first_level, (long long)P.dec_rate};
+        EdgeCtx e{pos_in_lds ? s_pos : pos, w_in_lds ? s_tick : nullptr, R, nb, first_level, (long long)P.dec_rate};
         if (P.decoder == SDR_DEC_SOMFY)
             rule_somfy(e, P, &ls, cap, s_bits);
         else if (P.decoder == SDR_DEC_BERNER)
