@@ -282,12 +282,44 @@ struct EdgeCtx {
     long long nb;
     int first_level;
     long long rate_hz;
+    int wave;                // device: all 64 lanes of the wavefront run the rule (EdgeReader may broadcast)
 };
 SDR_HD inline long long tick_of(const EdgeCtx& e, long long k)
 {
     if (e.ticks) return e.ticks[k];
     return ((long long)e.pos[k] * 1000000LL) / e.rate_hz;
 }
+
+// Edge k's tick and position for the rule loops.  On the device, when the whole wavefront
+// runs the rule, 64 edges at a time sit one per lane in registers and are handed out with
+// v_readlane (uniform index): no LDS round trip inside the sequential loop.
+struct EdgeReader {
+    const EdgeCtx& e;
+    long long c0, treg;
+    int32_t preg;
+    SDR_HD explicit EdgeReader(const EdgeCtx& e_) : e(e_), c0(-1), treg(0), preg(0) {}
+    SDR_HD void get(long long k, long long& tick, long long& at)
+    {
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (e.wave) {
+            if (c0 < 0 || k < c0 || k >= c0 + 64) {
+                c0 = k & ~63LL;
+                const long long idx = c0 + (long long)(threadIdx.x & 63);
+                treg = idx < e.R ? tick_of(e, idx) : 0;
+                preg = idx <= e.R ? e.pos[idx] : 0;
+            }
+            const int l = (int)(k - c0);
+            const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)treg, l);
+            const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)((unsigned long long)treg >> 32), l);
+            tick = (long long)(((unsigned long long)hi << 32) | lo);
+            at = __builtin_amdgcn_readlane(preg, l);
+            return;
+        }
+#endif
+        tick = tick_of(e, k);
+        at = e.pos[k];
+    }
+};
 
 SDR_HD inline bool in_range(long long d, long long a, long long b) { return d >= a && d < b; }
 
@@ -389,9 +421,11 @@ SDR_HD inline void rule_somfy(const EdgeCtx& e, const BackParams& P, DecState* s
     };
     int level = e.first_level;
     if (level == 1) event(1, 0);
+    EdgeReader rd(e);
     for (long long k = 1; k < e.R; ++k) {
-        long long tick = tick_of(e, k);
-        if (tick - prev_tick > wd) watchdog(e.pos[k]);
+        long long tick, at;
+        rd.get(k, tick, at);
+        if (tick - prev_tick > wd) watchdog(at);
         level ^= 1;
         event(level, tick);
         prev_tick = tick;
@@ -435,9 +469,12 @@ SDR_HD inline void rule_berner(const EdgeCtx& e, const BackParams& P, DecState* 
         }
     };
     if (level == 1) event(1, 0, 0);
+    EdgeReader rd(e);
     for (long long k = 1; k < e.R; ++k) {
         level ^= 1;
-        event(level, tick_of(e, k), e.pos[k]);
+        long long tick, at;
+        rd.get(k, tick, at);
+        event(level, tick, at);
     }
 }
 
@@ -480,9 +517,11 @@ SDR_HD inline void rule_mumbi(const EdgeCtx& e, const BackParams& P, DecState* s
         }
     };
     if (level == 1) event(1, 0);
+    EdgeReader rd(e);
     for (long long k = 1; k < e.R; ++k) {
-        long long tick = tick_of(e, k);
-        if (tick - prev_tick > wd) watchdog(e.pos[k]);
+        long long tick, at;
+        rd.get(k, tick, at);
+        if (tick - prev_tick > wd) watchdog(at);
         level ^= 1;
         event(level, tick);
         prev_tick = tick;
@@ -536,9 +575,11 @@ SDR_HD inline void rule_kwmobile(const EdgeCtx& e, const BackParams& P, DecState
         }
     };
     if (level == 1) event(1, 0);
+    EdgeReader rd(e);
     for (long long k = 1; k < e.R; ++k) {
-        long long tick = tick_of(e, k);
-        if (tick - prev_tick > wd) watchdog(e.pos[k]);
+        long long tick, at;
+        rd.get(k, tick, at);
+        if (tick - prev_tick > wd) watchdog(at);
         level ^= 1;
         event(level, tick);
         prev_tick = tick;
@@ -602,9 +643,11 @@ SDR_HD inline void rule_baldr(const EdgeCtx& e, const BackParams& P, DecState* s
         }
     };
     if (level == 1) event(1, 0);
+    EdgeReader rd(e);
     for (long long k = 1; k < e.R; ++k) {
-        long long tick = tick_of(e, k);
-        if (tick - prev_tick > wd) watchdog(e.pos[k]);
+        long long tick, at;
+        rd.get(k, tick, at);
+        if (tick - prev_tick > wd) watchdog(at);
         level ^= 1;
         event(level, tick);
         prev_tick = tick;

@@ -306,8 +306,11 @@ __global__ void __launch_bounds__(BK_THREADS, 6) k_backend(BackParams P)
             wave_stream_decode(P, cap, WidthsFromPos{pos, P.dec_rate}, pos, R, first_level, last_level, any_one, L,
                                &ls);
         for (int k = tid; k < ls.n_cur; k += 64) gcur[k] = s_cur[k];
-    } else if (tid == 0) {
-        EdgeCtx e{pos_in_lds ? s_pos : pos, w_in_lds ? s_tick : nullptr, R, nb, first_level, (long long)P.dec_rate};
+    } else {
+        // all 64 lanes of wavefront 0 run the rule on identical (wave-uniform) values: control flow is
+        // scalar branches instead of exec masking, every LDS read is a broadcast; the redundant stores
+        // hit the same addresses with the same data
+        EdgeCtx e{pos_in_lds ? s_pos : pos, w_in_lds ? s_tick : nullptr, R, nb, first_level, (long long)P.dec_rate, 1};
         if (P.decoder == SDR_DEC_SOMFY)
             rule_somfy(e, P, &ls, cap, s_bits);
         else if (P.decoder == SDR_DEC_BERNER)

@@ -87,7 +87,7 @@ extern "C" SDR_API int sdr_selftest_dec_work(void* p, const int8_t* bits, size_t
                           d->cur.data(), &d->st, d->scratch.data());
         else {
             std::vector<unsigned char> sb(512);
-            EdgeCtx e{pos.data(), nullptr, R, nb, first_level, (long long)d->rate};
+            EdgeCtx e{pos.data(), nullptr, R, nb, first_level, (long long)d->rate, 0};
             if (d->decoder == SDR_DEC_SOMFY) rule_somfy(e, P, &d->st, 0, sb.data());
             if (d->decoder == SDR_DEC_BERNER) rule_berner(e, P, &d->st, 0, sb.data());
             if (d->decoder == SDR_DEC_MUMBI) rule_mumbi(e, P, &d->st, 0, sb.data());
