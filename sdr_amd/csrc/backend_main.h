@@ -133,59 +133,83 @@ __global__ void __launch_bounds__(BK_THREADS, 6) k_backend(BackParams P)
 
     // ---- phase 1: run-length ------------------------------------------------
     int32_t* pos = P.runs + (long long)cap * (P.runs_cap + 2);
-    // Short rows (<= 8192 bytes, the batch case): every thread owns 32 bytes, held in
+    // Aligned rows, 8 KiB per round: every thread owns 32 bytes, held in
     // registers as 8 dwords straight from global memory; edges come from word arithmetic
     // (d = w ^ (w << 8 | previous byte); a byte of d is non-zero where the level changes)
     // instead of a byte-at-a-time walk through LDS, and the run starts are kept in LDS too
     // so that the widths do not wait on a global write/read round trip.
-    const bool fast = nb <= BK_BYTES_LDS && ((reinterpret_cast<uintptr_t>(bits) & 15) == 0) && (P.bits_stride & 31) == 0;
+    const bool fast = ((reinterpret_cast<uintptr_t>(bits) & 15) == 0) && (P.bits_stride & 31) == 0;
     int32_t* s_pos = reinterpret_cast<int32_t*>(s_B);   // [2048], free until phase 2 needs its sort scratch
     long long R = 0;
     bool runs_overflow = false;
     bool w_in_lds = false, pos_in_lds = false;
     int first_level = 0, last_level = 0;
     if (fast) {
-        const int j0 = tid * 32;
-        unsigned wd[8];
-        int valid = (int)nb - j0;
-        valid = valid < 0 ? 0 : (valid > 32 ? 32 : valid);
-        if (j0 < P.bits_stride && valid > 0) {
-            const uint4 a = *reinterpret_cast<const uint4*>(bits + j0), b = *reinterpret_cast<const uint4*>(bits + j0 + 16);
-            wd[0] = a.x; wd[1] = a.y; wd[2] = a.z; wd[3] = a.w;
-            wd[4] = b.x; wd[5] = b.y; wd[6] = b.z; wd[7] = b.w;
-        } else {
+        if (tid == 0) {
+            pos[0] = 0;
+            s_pos[0] = 0;
+        }
+        long long rbase = 0;   // edges found in the blocks before this one
+        for (long long blk = 0; blk < nb; blk += BK_BYTES_LDS) {   // long rows (channelizer): 8 KiB at a time
+            const long long j0 = blk + tid * 32;
+            unsigned wd[8];
+            long long vl = nb - j0;
+            const int valid = vl < 0 ? 0 : (vl > 32 ? 32 : (int)vl);
+            if (valid > 0) {
+                const uint4 a = *reinterpret_cast<const uint4*>(bits + j0), b = *reinterpret_cast<const uint4*>(bits + j0 + 16);
+                wd[0] = a.x; wd[1] = a.y; wd[2] = a.z; wd[3] = a.w;
+                wd[4] = b.x; wd[5] = b.y; wd[6] = b.z; wd[7] = b.w;
+            } else {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) wd[k] = 0;
-        }
-        unsigned prevb = (valid > 0) ? (j0 > 0 ? (unsigned)(unsigned char)bits[j0 - 1] : (wd[0] & 0xffu)) : 0u;
-        unsigned nz[8];
-        int cnt = 0;
+                for (int k = 0; k < 8; ++k) wd[k] = 0;
+            }
+            unsigned prevb = (valid > 0) ? (j0 > 0 ? (unsigned)(unsigned char)bits[j0 - 1] : (wd[0] & 0xffu)) : 0u;
+            unsigned nz[8];
+            int cnt = 0;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const unsigned d = wd[k] ^ ((wd[k] << 8) | prevb);
-            unsigned m = (((d & 0x7f7f7f7fu) + 0x7f7f7f7fu) | d) & 0x80808080u;   // bit 7 of every non-zero byte
-            const int left = valid - 4 * k;                                      // bytes of this word inside the row
-            if (left <= 0)
-                m = 0;
-            else if (left < 4)
-                m &= (1u << (8 * left)) - 1u;
-            nz[k] = m;
-            cnt += __builtin_popcount(m);
-            prevb = wd[k] >> 24;
+            for (int k = 0; k < 8; ++k) {
+                const unsigned d = wd[k] ^ ((wd[k] << 8) | prevb);
+                unsigned m = (((d & 0x7f7f7f7fu) + 0x7f7f7f7fu) | d) & 0x80808080u;   // bit 7 of every non-zero byte
+                const int left = valid - 4 * k;                                      // bytes of this word inside the row
+                if (left <= 0)
+                    m = 0;
+                else if (left < 4)
+                    m &= (1u << (8 * left)) - 1u;
+                nz[k] = m;
+                cnt += __builtin_popcount(m);
+                prevb = wd[k] >> 24;
+            }
+            int incl = cnt;
+            for (int off = 1; off < 64; off <<= 1) {
+                int t = __shfl_up(incl, off);
+                if (lane >= off) incl += t;
+            }
+            if (lane == 63) s_wtot[wv] = incl;
+            __syncthreads();
+            int wbase = 0, total = 0;
+            for (int w = 0; w < 4; ++w) {
+                if (w < wv) wbase += s_wtot[w];
+                total += s_wtot[w];
+            }
+            long long w = 1 + rbase + wbase + incl - cnt;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                unsigned m = nz[k];
+                while (m) {
+                    const int by = __builtin_ctz(m) >> 3;
+                    const int32_t at = (int32_t)(j0 + 4 * k + by);
+                    if (w < P.runs_cap) {
+                        pos[w] = at;
+                        if (w < 2048) s_pos[w] = at;
+                    }
+                    ++w;
+                    m &= m - 1;
+                }
+            }
+            rbase += total;
+            __syncthreads();   // s_wtot is rewritten by the next block
         }
-        int incl = cnt;
-        for (int off = 1; off < 64; off <<= 1) {
-            int t = __shfl_up(incl, off);
-            if (lane >= off) incl += t;
-        }
-        if (lane == 63) s_wtot[wv] = incl;
-        __syncthreads();
-        int wbase = 0, total = 0;
-        for (int w = 0; w < 4; ++w) {
-            if (w < wv) wbase += s_wtot[w];
-            total += s_wtot[w];
-        }
-        R = nb > 0 ? (long long)total + 1 : 0;
+        R = nb > 0 ? rbase + 1 : 0;
         if (R > P.runs_cap) {
             runs_overflow = true;
             R = P.runs_cap;
@@ -194,25 +218,6 @@ __global__ void __launch_bounds__(BK_THREADS, 6) k_backend(BackParams P)
         pos_in_lds = R + 1 <= 2048;
         first_level = nb > 0 ? (bits[0] != 0) : 0;
         last_level = nb > 0 ? (bits[nb - 1] != 0) : 0;
-        if (tid == 0) {
-            pos[0] = 0;
-            s_pos[0] = 0;
-        }
-        long long w = 1 + wbase + incl - cnt;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            unsigned m = nz[k];
-            while (m) {
-                const int by = __builtin_ctz(m) >> 3;
-                const int32_t at = j0 + 4 * k + by;
-                if (w < R) {
-                    pos[w] = at;
-                    if (w < 2048) s_pos[w] = at;
-                }
-                ++w;
-                m &= m - 1;
-            }
-        }
         if (tid == 0) {
             pos[R] = (int32_t)nb;
             if (R < 2048) s_pos[R] = (int32_t)nb;
