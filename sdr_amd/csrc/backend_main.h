@@ -68,12 +68,17 @@ __global__ void __launch_bounds__(BK_THREADS, 6) k_backend(BackParams P)
         const int per = (nt + BK_THREADS - 1) / BK_THREADS;
         const int t0 = tid * per, t1 = (t0 + per < nt) ? t0 + per : nt;
         int has = 0, last = 0, myfe = -1;
-        for (int i = t0; i < t1; ++i)
-            if (ts[i].first_evt >= 0) {
-                if (!has) myfe = ts[i].first_evt;
+        const long long* ts64 = reinterpret_cast<const long long*>(ts);   // (first_evt, last_state) as one 8-B load
+#pragma unroll 8
+        for (int i = t0; i < t1; ++i) {
+            const long long v = ts64[i];
+            const int fe = (int)v;
+            if (fe >= 0) {
+                if (!has) myfe = fe;
                 has = 1;
-                last = ts[i].last_state;
+                last = (int)(v >> 32);
             }
+        }
         // nearest earlier thread that saw an event: ballot inside the wave, a
         // 4-entry table across waves
         const unsigned long long mh = __ballot(has), ml = __ballot(last);
@@ -97,10 +102,12 @@ __global__ void __launch_bounds__(BK_THREADS, 6) k_backend(BackParams P)
                     break;
                 }
         int8_t* wbits = bits + P.patch_off;
+#pragma unroll 4
         for (int i = t0; i < t1; ++i) {
+            const long long v = ts64[i];
             long long o_beg = (long long)i * P.tile_out;
             long long o_end = o_beg + P.tile_out < nout ? o_beg + P.tile_out : nout;
-            long long fe = ts[i].first_evt;
+            long long fe = (int)v;
             if (carry == 1) {
                 long long e = fe >= 0 ? fe : o_end;
                 long long o = o_beg < P.keep_c0 ? P.keep_c0 : o_beg;
@@ -110,7 +117,7 @@ __global__ void __launch_bounds__(BK_THREADS, 6) k_backend(BackParams P)
                 }
                 for (; o < e; o += P.keep_n) wbits[(o - P.keep_c0) / P.keep_n] = 1;
             }
-            if (fe >= 0) carry = ts[i].last_state;
+            if (fe >= 0) carry = (int)(v >> 32);
         }
         __syncthreads();
         // the owner of the last tile hands the carry-out to thread 0 through LDS;
