@@ -10,7 +10,7 @@ taps = chain.low_pass(1.0, bench.FS, 20e3, 40e3)
 fmt = os.environ.get("SDR_FMT", "fc32")
 if fmt == "cu8":
     iq = torch.randint(100, 156, (ncap, bench.N_PER_CAPTURE, 2), device=dev, dtype=torch.uint8)
-c = chain.Chain(bench.FS, decim=50, center_freq=bench.F_OFF, taps=taps, decoder=chain.DEC_NONE, max_batch=ncap, max_frames=4, max_samples=bench.N_PER_CAPTURE, input_format=fmt)
+c = chain.Chain(bench.FS, decim=int(os.environ.get("SDR_D", "50")), center_freq=bench.F_OFF, taps=taps, decoder=chain.DEC_NONE, max_batch=ncap, max_frames=4, max_samples=bench.N_PER_CAPTURE, input_format=fmt)
 c.profile_enable(True)
 for _ in range(60):
     c.batch_process(iq)
