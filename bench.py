@@ -236,6 +236,89 @@ def cu8_workload(torch, dev, iq, pkts, taps, steps=20):
             "verified": "all captures decode to the transmitted packets"}
 
 
+def tfa_fsk_workload(torch, dev, skip_cpu, ncap=64, n=1 << 20, fs=2e6, dev_hz=60e3, steps=20):
+    """Secondary line: BASELINE.json configs[2] / SURVEY 8d-3 -- TFA 30.3180.IT 2-level FSK at 38400 Bd:
+    LPF (27 taps, TFA/decoder.grc:1163-1234) at decimation 1 -> quadrature_demod (TFA/decoder.grc:450-481)
+    -> threshold +-0.2 -> slicer -> TFA stream decoder at 2 MS/s (symbol length from the sync pairs,
+    CRC-8).  One sliced byte per input sample: 9 algorithmic bytes per sample."""
+    from sdr_amd import chain, synth, _lib
+    rng = np.random.default_rng(30)
+    nenv = 8
+    envs, pkts = np.zeros((nenv, n), np.float32), []
+    for e in range(nenv):
+        sym, pk = [], []
+        for _ in range(18):
+            p = synth.tfa_packet(ident=int(rng.integers(0, 65536)), temp_c=float(rng.integers(-300, 500)) / 10,
+                                 humidity=int(rng.integers(0, 100)))
+            pk.append(p)
+            sym += synth.tfa_symbols(synth.tfa_bits(p), rng, reset_gap_us=20000.0 + 2000.0 * rng.random())
+        env = synth.envelope(sym, fs, lead_in_us=800.0)
+        if env.size > n - 2500:
+            raise SystemExit("tfa workload: envelope does not fit")
+        envs[e, :env.size] = env
+        pkts.append(pk)
+    iq = torch.empty((ncap, n, 2), dtype=torch.float32, device=dev)
+    g = torch.Generator(device=dev)
+    g.manual_seed(30)
+    for i in range(ncap):
+        f = torch.from_numpy(envs[i % nenv]).to(dev).to(torch.float64) * 2.0 - 1.0
+        ph = torch.cumsum(f, 0) * (2 * np.pi * dev_hz / fs) + float(rng.random() * 2 * np.pi)
+        iq[i, :, 0] = (0.8 * torch.cos(ph)).to(torch.float32)
+        iq[i, :, 1] = (0.8 * torch.sin(ph)).to(torch.float32)
+        iq[i] += 0.01 * torch.randn((n, 2), generator=g, device=dev, dtype=torch.float32)
+    taps = chain.low_pass(1, fs, 500e3, 250e3, chain.WIN_BLACKMAN)
+    gain = np.float32(fs / (2 * np.pi * dev_hz))
+    c = chain.Chain(fs, decim=1, taps=taps, demod=chain.DEMOD_QUAD, demod_gain=gain, thr=(-0.2, 0.2),
+                    decoder=chain.DEC_TFA_GRC, max_batch=ncap, max_frames=32, max_samples=n)
+    c.set_stream(torch.cuda.current_stream().cuda_stream)
+    for _ in range(3):
+        c.batch_process(iq)
+    torch.cuda.synchronize()
+    c.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        c.batch_process(iq)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    front_ms, back_ms = c.profile_read()
+    frames = c.fetch_frames()
+    n_ok = 0
+    for i in range(ncap):
+        n_ok += [f.packet() for f in frames if f.capture == i and f.status == _lib.FRAME_OK] == pkts[i % nenv]
+    if n_ok != ncap:
+        raise SystemExit("TFA FSK: only %d of %d captures decoded to the transmitted packets" % (n_ok, ncap))
+    fk = float(np.mean(front_ms))
+    bps = 9.0
+    ach = bps * ncap * n / (fk * 1e-3) / 1e9
+    out = {"value": round(ncap * n / dt / 1e6, 1), "unit": "Msps", "ms_per_step": round(dt * 1e3, 4), "captures": ncap,
+           "samples_per_capture": n, "sample_rate": fs, "ntaps": int(taps.size), "decim": 1, "packets_per_capture": 18,
+           "chain": "fir_filter_ccf->quadrature_demod->threshold->slicer->tfa_stream_decoder",
+           "roofline": {"bound": "hbm", "kernel": "front end (k_frontend*)", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "kernel_ms": round(fk, 4),
+                        "backend_kernel_ms": round(float(np.mean(back_ms)), 4), "bytes_per_launch": bps * ncap * n},
+           "verified": "all captures decode to the transmitted packets (CRC-8 ok)"}
+    if not skip_cpu:
+        from oracle import decoders as odec
+        from oracle import dsp as odsp
+        bits = c.fetch_bits().reshape(ncap, -1)
+        x = iq[0].cpu().numpy().view(np.complex64).reshape(-1)
+        t0 = time.perf_counter()
+        want = odsp.quad_demod(odsp.fir_ccf(x, taps, 1), gain)
+        wb, _, _ = odsp.slice_bits(want, 1.0, -0.2, 0.2, 1)
+        o = odec.TFAStreamDecoder(sample_rate=int(fs), nan_guard=True)
+        o.work([wb])
+        tc = time.perf_counter() - t0
+        mine = [f for f in frames if f.capture == 0]
+        if not np.array_equal(bits[0], wb) or len(mine) != len(o.frames) or \
+                [f["packet"] for f in o.frames if f["status"] == "ok"] != [f.packet() for f in mine if f.status == 0]:
+            raise SystemExit("TFA FSK: capture 0 differs from the oracle")
+        out["cpu_baseline"] = {"value": round(n / tc / 1e6, 2), "unit": "Msps", "cores": 1, "kind": "port",
+                               "sample": "capture 0 (2^20 samples), oracle C blocks + numpy TFA decoder, %.2f s" % tc}
+        out["verified"] += "; capture 0 bit-exact vs oracle (sliced bytes, frames)"
+    c.close()
+    return out
+
+
 def mixed_emitters_workload(torch, dev, skip_cpu, ncap=1250, n=N_PER_CAPTURE, fs=FS, steps=10):
     """Secondary line: BASELINE.json configs[3] as worded -- a batch of OOK/PWM captures from somfy RTS,
     berner and mumbi transmitters (one emitter per capture, random payloads; timings of the reference's
@@ -569,6 +652,7 @@ def main():
             other["fm_radio_wbfm"] = fm_workload(torch, dev, args.no_cpu_baseline)
             other["ook_r_shape_ts33c"] = r_shape_workload(torch, dev, args.no_cpu_baseline)
             other["wideband_pfb64"] = pfb_workload(torch, dev, args.no_cpu_baseline)
+            other["tfa_fsk_discriminator"] = tfa_fsk_workload(torch, dev, args.no_cpu_baseline)
             other["ook_batch_somfy_berner_mumbi"] = mixed_emitters_workload(torch, dev, args.no_cpu_baseline)
             line["other_workloads"] = other
         print(json.dumps(line))

@@ -157,20 +157,29 @@ __global__ void __launch_bounds__(BK_THREADS, 6) k_backend(BackParams P)
             s_pos[0] = 0;
         }
         long long rbase = 0;   // edges found in the blocks before this one
-        for (long long blk = 0; blk < nb; blk += BK_BYTES_LDS) {   // long rows (channelizer): 8 KiB at a time
+        // one block = 32 bytes per thread + the byte in front of them; the next block's loads are
+        // issued before this block is scanned (long rows: the load latency was 2/3 of a round)
+        auto fetch_blk = [&](long long blk, unsigned (&o)[8], unsigned& pbyte) {
             const long long j0 = blk + tid * 32;
-            unsigned wd[8];
-            long long vl = nb - j0;
-            const int valid = vl < 0 ? 0 : (vl > 32 ? 32 : (int)vl);
-            if (valid > 0) {
+            if (j0 < nb) {
                 const uint4 a = *reinterpret_cast<const uint4*>(bits + j0), b = *reinterpret_cast<const uint4*>(bits + j0 + 16);
-                wd[0] = a.x; wd[1] = a.y; wd[2] = a.z; wd[3] = a.w;
-                wd[4] = b.x; wd[5] = b.y; wd[6] = b.z; wd[7] = b.w;
+                o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w;
+                o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+                pbyte = j0 > 0 ? (unsigned)(unsigned char)bits[j0 - 1] : (o[0] & 0xffu);
             } else {
 #pragma unroll
-                for (int k = 0; k < 8; ++k) wd[k] = 0;
+                for (int k = 0; k < 8; ++k) o[k] = 0;
+                pbyte = 0;
             }
-            unsigned prevb = (valid > 0) ? (j0 > 0 ? (unsigned)(unsigned char)bits[j0 - 1] : (wd[0] & 0xffu)) : 0u;
+        };
+        unsigned wd[8], prevb;
+        fetch_blk(0, wd, prevb);
+        for (long long blk = 0; blk < nb; blk += BK_BYTES_LDS) {   // long rows (channelizer): 8 KiB at a time
+            const long long j0 = blk + tid * 32;
+            long long vl = nb - j0;
+            const int valid = vl < 0 ? 0 : (vl > 32 ? 32 : (int)vl);
+            unsigned nwd[8], nprevb;
+            fetch_blk(blk + BK_BYTES_LDS, nwd, nprevb);
             unsigned nz[8];
             int cnt = 0;
 #pragma unroll
@@ -214,6 +223,9 @@ __global__ void __launch_bounds__(BK_THREADS, 6) k_backend(BackParams P)
                 }
             }
             rbase += total;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) wd[k] = nwd[k];
+            prevb = nprevb;
             __syncthreads();   // s_wtot is rewritten by the next block
         }
         R = nb > 0 ? rbase + 1 : 0;
