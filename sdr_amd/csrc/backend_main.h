@@ -16,7 +16,7 @@ __global__ void __launch_bounds__(BK_THREADS, 6) k_backend(BackParams P)
     __shared__ __align__(16) unsigned char s_B[SDR_CUR_CAP * 8];
     __shared__ __align__(16) unsigned char s_C[SDR_CUR_CAP * 8];
     __shared__ int s_cnt[BK_THREADS];
-    __shared__ int s_wtot[4];
+    __shared__ int s_wtot[8];   // two sets of per-wave totals, alternating by round
     __shared__ int s_fe[4];
     __shared__ unsigned int s_words[64];
     __shared__ unsigned char s_par[256];
@@ -157,33 +157,31 @@ __global__ void __launch_bounds__(BK_THREADS, 6) k_backend(BackParams P)
             s_pos[0] = 0;
         }
         long long rbase = 0;   // edges found in the blocks before this one
-        // one block = 32 bytes per thread + the byte in front of them; the next block's loads are
-        // issued before this block is scanned (long rows: the load latency was 2/3 of a round)
-        auto fetch_blk = [&](long long blk, unsigned (&o)[8], unsigned& pbyte) {
-            const long long j0 = blk + tid * 32;
-            if (j0 < nb) {
-                const uint4 a = *reinterpret_cast<const uint4*>(bits + j0), b = *reinterpret_cast<const uint4*>(bits + j0 + 16);
-                o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w;
-                o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
-                pbyte = j0 > 0 ? (unsigned)(unsigned char)bits[j0 - 1] : (o[0] & 0xffu);
-            } else {
+        // one block = RL_W words (64 bytes) per thread + the byte in front of them; rows are padded
+        // to 32 bytes, so every 16-byte piece that starts inside the row can be read whole
+        constexpr int RL_W = 16, RL_BYTES = 4 * RL_W, RL_BLK = BK_THREADS * RL_BYTES;
+        auto fetch_blk = [&](long long blk, unsigned (&o)[RL_W], unsigned& pbyte) {
+            const long long j0 = blk + tid * RL_BYTES;
 #pragma unroll
-                for (int k = 0; k < 8; ++k) o[k] = 0;
-                pbyte = 0;
+            for (int q = 0; q < RL_W / 4; ++q) {
+                uint4 a = make_uint4(0u, 0u, 0u, 0u);
+                if (j0 + 16 * q < nb) a = *reinterpret_cast<const uint4*>(bits + j0 + 16 * q);
+                o[4 * q] = a.x; o[4 * q + 1] = a.y; o[4 * q + 2] = a.z; o[4 * q + 3] = a.w;
             }
+            pbyte = 0;
+            if (j0 < nb) pbyte = j0 > 0 ? (unsigned)(unsigned char)bits[j0 - 1] : (o[0] & 0xffu);
         };
-        unsigned wd[8], prevb;
+        unsigned wd[RL_W], prevb;
+        int par = 0;
         fetch_blk(0, wd, prevb);
-        for (long long blk = 0; blk < nb; blk += BK_BYTES_LDS) {   // long rows (channelizer): 8 KiB at a time
-            const long long j0 = blk + tid * 32;
+        for (long long blk = 0; blk < nb; blk += RL_BLK) {   // long rows (channelizer, D=1 chains): 16 KiB at a time
+            const long long j0 = blk + tid * RL_BYTES;
             long long vl = nb - j0;
-            const int valid = vl < 0 ? 0 : (vl > 32 ? 32 : (int)vl);
-            unsigned nwd[8], nprevb;
-            fetch_blk(blk + BK_BYTES_LDS, nwd, nprevb);
-            unsigned nz[8];
+            const int valid = vl < 0 ? 0 : (vl > RL_BYTES ? RL_BYTES : (int)vl);
+            unsigned nz[RL_W];
             int cnt = 0;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
+            for (int k = 0; k < RL_W; ++k) {
                 const unsigned d = wd[k] ^ ((wd[k] << 8) | prevb);
                 unsigned m = (((d & 0x7f7f7f7fu) + 0x7f7f7f7fu) | d) & 0x80808080u;   // bit 7 of every non-zero byte
                 const int left = valid - 4 * k;                                      // bytes of this word inside the row
@@ -195,38 +193,38 @@ __global__ void __launch_bounds__(BK_THREADS, 6) k_backend(BackParams P)
                 cnt += __builtin_popcount(m);
                 prevb = wd[k] >> 24;
             }
-            int incl = cnt;
-            for (int off = 1; off < 64; off <<= 1) {
-                int t = __shfl_up(incl, off);
-                if (lane >= off) incl += t;
-            }
-            if (lane == 63) s_wtot[wv] = incl;
-            __syncthreads();
+            // the masks are all this block still needs: the next block's loads go out now and are
+            // in flight during the scan and the edge stores (issued any earlier, the wait for this
+            // block's words would also wait for them)
+            fetch_blk(blk + RL_BLK, wd, prevb);
+            const int incl = wave_incl_scan_dpp(cnt);
+            int* const wt = s_wtot + (par << 2);
+            par ^= 1;
+            if (lane == 63) wt[wv] = incl;
+            __syncthreads();   // the only barrier of a round: the next round writes the other set of totals
             int wbase = 0, total = 0;
             for (int w = 0; w < 4; ++w) {
-                if (w < wv) wbase += s_wtot[w];
-                total += s_wtot[w];
+                if (w < wv) wbase += wt[w];
+                total += wt[w];
             }
             long long w = 1 + rbase + wbase + incl - cnt;
+            if (cnt) {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                unsigned m = nz[k];
-                while (m) {
-                    const int by = __builtin_ctz(m) >> 3;
-                    const int32_t at = (int32_t)(j0 + 4 * k + by);
-                    if (w < P.runs_cap) {
-                        pos[w] = at;
-                        if (w < 2048) s_pos[w] = at;
+                for (int k = 0; k < RL_W; ++k) {
+                    unsigned m = nz[k];
+                    while (m) {
+                        const int by = __builtin_ctz(m) >> 3;
+                        const int32_t at = (int32_t)(j0 + 4 * k + by);
+                        if (w < P.runs_cap) {
+                            pos[w] = at;
+                            if (w < 2048) s_pos[w] = at;
+                        }
+                        ++w;
+                        m &= m - 1;
                     }
-                    ++w;
-                    m &= m - 1;
                 }
             }
             rbase += total;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) wd[k] = nwd[k];
-            prevb = nprevb;
-            __syncthreads();   // s_wtot is rewritten by the next block
         }
         R = nb > 0 ? rbase + 1 : 0;
         if (R > P.runs_cap) {
@@ -257,11 +255,7 @@ __global__ void __launch_bounds__(BK_THREADS, 6) k_backend(BackParams P)
         }
     }
     // block exclusive scan of the per-thread edge counts
-    int incl = cnt;
-    for (int off = 1; off < 64; off <<= 1) {
-        int t = __shfl_up(incl, off);
-        if (lane >= off) incl += t;
-    }
+    const int incl = wave_incl_scan_dpp(cnt);
     if (lane == 63) s_wtot[wv] = incl;
     __syncthreads();
     int wbase = 0, total = 0;
