@@ -400,12 +400,13 @@ def mixed_emitters_workload(torch, dev, skip_cpu, ncap=1250, n=N_PER_CAPTURE, fs
     bk = 3.0 * float(np.mean(back_ms))
     bps = 8.0 + 1.0 / D
     ach = bps * ncap * n / (fk * 1e-3) / 1e9
+    traffic, _src = pmc_traffic("k_frontend<true, false> fc32 D=10", "ook_batch_somfy_berner_mumbi captures=%d" % ncap)
     out = {"value": round(ncap * n / dt / 1e6, 1), "unit": "Msps", "ms_per_step": round(dt * 1e3, 4), "captures": ncap,
            "samples_per_capture": n, "sample_rate": fs, "ntaps": int(taps.size), "decim": D,
            "emitters": "somfy RTS / berner / mumbi, one per capture", "decoders_per_capture": 3,
            "chain": "xlating_fir->mag2->threshold->slicer->{somfy, berner, mumbi} rule decoders",
            "roofline": {"bound": "hbm", "kernel": "k_frontend<true, false>", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "kernel_ms": round(fk, 4),
+                        "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "kernel_ms": round(fk, 4),
                         "backend_kernel_ms": round(bk, 4), "bytes_per_launch": bps * ncap * n},
            "verified": "every capture decodes to its transmitted payload under its own decoder"}
     if not skip_cpu:
@@ -515,7 +516,7 @@ def pmc_traffic(kernel_key, workload_tag):
     """HBM bytes per launch of one kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
     WRITE_SIZE over this same command; counters cannot be read from inside the process).  None if the
     committed workload differs from the one being run."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_j_pmc.json")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_m_pmc.json")
     try:
         with open(path) as f:
             rec = json.load(f)["kernels"][kernel_key]
@@ -523,7 +524,7 @@ def pmc_traffic(kernel_key, workload_tag):
         return None, None
     if workload_tag not in rec.get("workload", ""):
         return None, None
-    return int(rec["hbm_bytes"]), "profiles/r01_j_pmc.json"
+    return int(rec["hbm_bytes"]), "profiles/r01_m_pmc.json"
 
 
 def main():
