@@ -10,6 +10,105 @@
 
 #define BK_BYTES_LDS 8192
 
+// Run starts of bits[b0, b1) (b0 a multiple of the 16-KiB round, b1 <= nb): entry number w (counted from 1
+// inside this range) goes to pos[w] (and to s_pos[w] while w < 2048, if s_pos is given).  Every thread
+// owns 64 bytes per round, held in registers as 16 dwords straight from global memory; edges come from
+// word arithmetic (d = w ^ (w << 8 | previous byte); a byte of d is non-zero where the level changes).
+// Returns the number of edges; called by all BK_THREADS threads.
+__device__ __forceinline__ long long rl_blocks(const int8_t* __restrict__ bits, const long long nb, const long long b0,
+                                               const long long b1, int32_t* pos, const long long cap_w, int32_t* s_pos,
+                                               int* s_wtot)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+        long long rbase = 0;   // edges found in the blocks before this one
+        // one block = RL_W words (64 bytes) per thread + the byte in front of them; rows are padded
+        // to 32 bytes, so every 16-byte piece that starts inside the row can be read whole
+        constexpr int RL_W = 16, RL_BYTES = 4 * RL_W, RL_BLK = BK_THREADS * RL_BYTES;
+        auto fetch_blk = [&](long long blk, unsigned (&o)[RL_W], unsigned& pbyte) {
+            const long long j0 = blk + tid * RL_BYTES;
+#pragma unroll
+            for (int q = 0; q < RL_W / 4; ++q) {
+                uint4 a = make_uint4(0u, 0u, 0u, 0u);
+                if (j0 + 16 * q < nb) a = *reinterpret_cast<const uint4*>(bits + j0 + 16 * q);
+                o[4 * q] = a.x; o[4 * q + 1] = a.y; o[4 * q + 2] = a.z; o[4 * q + 3] = a.w;
+            }
+            pbyte = 0;
+            if (j0 < nb) pbyte = j0 > 0 ? (unsigned)(unsigned char)bits[j0 - 1] : (o[0] & 0xffu);
+        };
+        unsigned wd[RL_W], prevb;
+        int par = 0;
+        fetch_blk(b0, wd, prevb);
+        for (long long blk = b0; blk < b1; blk += RL_BLK) {   // long rows (channelizer, D=1 chains): 16 KiB at a time
+            const long long j0 = blk + tid * RL_BYTES;
+            long long vl = nb - j0;
+            const int valid = vl < 0 ? 0 : (vl > RL_BYTES ? RL_BYTES : (int)vl);
+            unsigned nz[RL_W];
+            int cnt = 0;
+#pragma unroll
+            for (int k = 0; k < RL_W; ++k) {
+                const unsigned d = wd[k] ^ ((wd[k] << 8) | prevb);
+                unsigned m = (((d & 0x7f7f7f7fu) + 0x7f7f7f7fu) | d) & 0x80808080u;   // bit 7 of every non-zero byte
+                const int left = valid - 4 * k;                                      // bytes of this word inside the row
+                if (left <= 0)
+                    m = 0;
+                else if (left < 4)
+                    m &= (1u << (8 * left)) - 1u;
+                nz[k] = m;
+                cnt += __builtin_popcount(m);
+                prevb = wd[k] >> 24;
+            }
+            // the masks are all this block still needs: the next block's loads go out now and are
+            // in flight during the scan and the edge stores (issued any earlier, the wait for this
+            // block's words would also wait for them)
+            if (blk + RL_BLK < b1) fetch_blk(blk + RL_BLK, wd, prevb);
+            const int incl = wave_incl_scan_dpp(cnt);
+            int* const wt = s_wtot + (par << 2);
+            par ^= 1;
+            if (lane == 63) wt[wv] = incl;
+            __syncthreads();   // the only barrier of a round: the next round writes the other set of totals
+            int wbase = 0, total = 0;
+            for (int w = 0; w < 4; ++w) {
+                if (w < wv) wbase += wt[w];
+                total += wt[w];
+            }
+            long long w = 1 + rbase + wbase + incl - cnt;
+            if (cnt) {
+#pragma unroll
+                for (int k = 0; k < RL_W; ++k) {
+                    unsigned m = nz[k];
+                    while (m) {
+                        const int by = __builtin_ctz(m) >> 3;
+                        const int32_t at = (int32_t)(j0 + 4 * k + by);
+                        if (w < cap_w) {
+                            pos[w] = at;
+                            if (s_pos && w < 2048) s_pos[w] = at;
+                        }
+                        ++w;
+                        m &= m - 1;
+                    }
+                }
+            }
+            rbase += total;
+        }
+        return rbase;
+}
+
+// Long rows: one workgroup per seg_bytes of a row finds that segment's run starts (absolute byte
+// positions) and leaves them, compacted, in the row's runs_seg slice from index seg*seg_bytes on
+// (a segment cannot hold more edges than bytes) with the count in seg_cnt; k_backend (phase_sel 2)
+// scans the counts and gathers.  Runs after the carries are patched (k_backend phase_sel 1).
+__global__ void __launch_bounds__(BK_THREADS) k_runs_seg(BackParams P)
+{
+    __shared__ int s_wtot[8];
+    const int seg = blockIdx.x, cap = blockIdx.y;
+    const int8_t* bits = P.bits + (long long)cap * P.bits_stride;
+    const long long b0 = (long long)seg * P.seg_bytes;
+    const long long b1 = b0 + P.seg_bytes < P.nb ? b0 + P.seg_bytes : P.nb;
+    long long n = 0;
+    if (b0 < b1) n = rl_blocks(bits, P.nb, b0, b1, P.runs_seg + (long long)cap * P.bits_stride + b0 - 1, P.seg_bytes + 1, nullptr, s_wtot);
+    if (threadIdx.x == 0) P.seg_cnt[(long long)cap * P.nseg + seg] = (int32_t)n;
+}
+
 __global__ void __launch_bounds__(BK_THREADS, 6) k_backend(BackParams P)
 {
     __shared__ __align__(16) unsigned char s_A[SDR_CUR_CAP * 8];
@@ -57,7 +156,7 @@ __global__ void __launch_bounds__(BK_THREADS, 6) k_backend(BackParams P)
             st->gap_short_limit = 775.0;
         }
         st->n_frames = 0;
-        st->first_evt = -1;
+        if (P.phase_sel != 2) st->first_evt = -1;   // phase_sel 2 follows a phase-0 launch that has set it
     }
     __syncthreads();
 
@@ -132,7 +231,7 @@ __global__ void __launch_bounds__(BK_THREADS, 6) k_backend(BackParams P)
             st->first_evt = fe;
         }
     }
-    if (!run_decoder || P.decoder == SDR_DEC_NONE) return;
+    if (!run_decoder || P.decoder == SDR_DEC_NONE || P.phase_sel == 1) return;
     __syncthreads();
 #ifdef SDR_BK_TIMING
     tk1 = __builtin_readcyclecounter();
@@ -156,76 +255,39 @@ __global__ void __launch_bounds__(BK_THREADS, 6) k_backend(BackParams P)
             pos[0] = 0;
             s_pos[0] = 0;
         }
-        long long rbase = 0;   // edges found in the blocks before this one
-        // one block = RL_W words (64 bytes) per thread + the byte in front of them; rows are padded
-        // to 32 bytes, so every 16-byte piece that starts inside the row can be read whole
-        constexpr int RL_W = 16, RL_BYTES = 4 * RL_W, RL_BLK = BK_THREADS * RL_BYTES;
-        auto fetch_blk = [&](long long blk, unsigned (&o)[RL_W], unsigned& pbyte) {
-            const long long j0 = blk + tid * RL_BYTES;
-#pragma unroll
-            for (int q = 0; q < RL_W / 4; ++q) {
-                uint4 a = make_uint4(0u, 0u, 0u, 0u);
-                if (j0 + 16 * q < nb) a = *reinterpret_cast<const uint4*>(bits + j0 + 16 * q);
-                o[4 * q] = a.x; o[4 * q + 1] = a.y; o[4 * q + 2] = a.z; o[4 * q + 3] = a.w;
-            }
-            pbyte = 0;
-            if (j0 < nb) pbyte = j0 > 0 ? (unsigned)(unsigned char)bits[j0 - 1] : (o[0] & 0xffu);
-        };
-        unsigned wd[RL_W], prevb;
-        int par = 0;
-        fetch_blk(0, wd, prevb);
-        for (long long blk = 0; blk < nb; blk += RL_BLK) {   // long rows (channelizer, D=1 chains): 16 KiB at a time
-            const long long j0 = blk + tid * RL_BYTES;
-            long long vl = nb - j0;
-            const int valid = vl < 0 ? 0 : (vl > RL_BYTES ? RL_BYTES : (int)vl);
-            unsigned nz[RL_W];
-            int cnt = 0;
-#pragma unroll
-            for (int k = 0; k < RL_W; ++k) {
-                const unsigned d = wd[k] ^ ((wd[k] << 8) | prevb);
-                unsigned m = (((d & 0x7f7f7f7fu) + 0x7f7f7f7fu) | d) & 0x80808080u;   // bit 7 of every non-zero byte
-                const int left = valid - 4 * k;                                      // bytes of this word inside the row
-                if (left <= 0)
-                    m = 0;
-                else if (left < 4)
-                    m &= (1u << (8 * left)) - 1u;
-                nz[k] = m;
-                cnt += __builtin_popcount(m);
-                prevb = wd[k] >> 24;
-            }
-            // the masks are all this block still needs: the next block's loads go out now and are
-            // in flight during the scan and the edge stores (issued any earlier, the wait for this
-            // block's words would also wait for them)
-            fetch_blk(blk + RL_BLK, wd, prevb);
-            const int incl = wave_incl_scan_dpp(cnt);
-            int* const wt = s_wtot + (par << 2);
-            par ^= 1;
-            if (lane == 63) wt[wv] = incl;
-            __syncthreads();   // the only barrier of a round: the next round writes the other set of totals
+        long long rbase;
+        if (P.phase_sel == 2) {
+            // the segments' run starts are already in runs_seg (k_runs_seg): scan the counts, one per
+            // thread, and move every segment's list to its place in the row's run table
+            const int32_t* sc = P.seg_cnt + (long long)cap * P.nseg;
+            const int c = tid < P.nseg ? sc[tid] : 0;
+            const int incl = wave_incl_scan_dpp(c);
+            if (lane == 63) s_wtot[wv] = incl;
+            __syncthreads();
             int wbase = 0, total = 0;
             for (int w = 0; w < 4; ++w) {
-                if (w < wv) wbase += wt[w];
-                total += wt[w];
+                if (w < wv) wbase += s_wtot[w];
+                total += s_wtot[w];
             }
-            long long w = 1 + rbase + wbase + incl - cnt;
-            if (cnt) {
-#pragma unroll
-                for (int k = 0; k < RL_W; ++k) {
-                    unsigned m = nz[k];
-                    while (m) {
-                        const int by = __builtin_ctz(m) >> 3;
-                        const int32_t at = (int32_t)(j0 + 4 * k + by);
-                        if (w < P.runs_cap) {
-                            pos[w] = at;
-                            if (w < 2048) s_pos[w] = at;
-                        }
-                        ++w;
-                        m &= m - 1;
+            s_cnt[tid] = wbase + incl - c;   // exclusive offset of segment tid
+            __syncthreads();
+            const int32_t* src = P.runs_seg + (long long)cap * P.bits_stride;
+            for (int sg = wv; sg < P.nseg; sg += BK_THREADS / 64) {
+                const int n_s = sc[sg];
+                const long long o_s = 1 + s_cnt[sg];
+                const int32_t* from = src + (long long)sg * P.seg_bytes;
+                for (int i = lane; i < n_s; i += 64) {
+                    const long long w = o_s + i;
+                    if (w < P.runs_cap) {
+                        const int32_t at = from[i];
+                        pos[w] = at;
+                        if (w < 2048) s_pos[w] = at;
                     }
                 }
             }
-            rbase += total;
-        }
+            rbase = total;
+        } else
+            rbase = rl_blocks(bits, nb, 0, nb, pos, P.runs_cap, s_pos, s_wtot);
         R = nb > 0 ? rbase + 1 : 0;
         if (R > P.runs_cap) {
             runs_overflow = true;

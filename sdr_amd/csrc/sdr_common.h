@@ -156,4 +156,10 @@ struct BackParams {
     int max_frames;
     const double* pow_m13;  // n^(-1/3)
     const double* log2n;    // log2(n)
+    // long rows: run starts found by k_runs_seg, one workgroup per seg_bytes of a row
+    int phase_sel;          // 0: all phases; 1: phase 0 only (carries); 2: phases 1-2, runs gathered from runs_seg
+    int nseg;
+    long long seg_bytes;    // multiple of the 16-KiB round
+    int32_t* runs_seg;      // per capture bits_stride ints: segment s keeps its edges from index s*seg_bytes on
+    int32_t* seg_cnt;       // per capture nseg counts
 };

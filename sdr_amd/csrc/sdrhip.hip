@@ -60,6 +60,8 @@ struct sdr_handle {
     TileSum* d_tsum = nullptr;
     int tsum_stride = 0;
     int32_t* d_runs = nullptr;
+    int32_t* d_runs_seg = nullptr;  // rows of SDR_SEG_MIN_ROW bytes and more: per-segment run starts (k_runs_seg)
+    int32_t* d_seg_cnt = nullptr;
     long long runs_cap = 0;
     double* d_cur = nullptr;
     DecState* d_st = nullptr;
@@ -109,6 +111,7 @@ struct sdr_handle {
     unsigned long long pcount = 0;
 };
 #define SDR_PROF_RING 256
+#define SDR_SEG_MIN_ROW (128 * 1024)   // sliced rows this long take the segment-parallel run-length path
 
 static thread_local std::string g_err;
 
@@ -438,7 +441,7 @@ extern "C" int sdr_destroy(sdr_handle* h)
     }
     if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
     void* ptrs[] = {h->d_rtaps, h->d_post_rtaps, h->d_nco_tab, h->d_atan_tab, h->d_pow, h->d_log2, h->d_iq,
-                    h->d_hist[0], h->d_hist[1], h->d_bits, h->d_tap, h->d_tap2, h->d_tsum, h->d_runs,
+                    h->d_hist[0], h->d_hist[1], h->d_bits, h->d_tap, h->d_tap2, h->d_tsum, h->d_runs, h->d_runs_seg, h->d_seg_cnt,
                     h->d_cur, h->d_st, h->d_frames, h->d_sq_y, h->d_sq_z, h->d_sq_cnt, h->d_sq_st,
                     h->d_post_hist[0], h->d_post_hist[1], h->d_pack, h->d_pfb_taps, h->d_pfb_tw};
     for (void* p : ptrs)
@@ -524,6 +527,10 @@ extern "C" int sdr_create(const sdr_chain_cfg* cfg, sdr_handle** out)
         HIPCHK(h, dev_alloc((void**)&h->d_tsum, (size_t)(B * h->tsum_stride) * sizeof(TileSum)));
         h->runs_cap = h->bits_stride;
         HIPCHK(h, dev_alloc((void**)&h->d_runs, (size_t)(B * (h->runs_cap + 2)) * sizeof(int32_t)));
+        if (h->bits_stride >= SDR_SEG_MIN_ROW) {
+            HIPCHK(h, dev_alloc((void**)&h->d_runs_seg, (size_t)(B * h->bits_stride) * sizeof(int32_t)));
+            HIPCHK(h, dev_alloc((void**)&h->d_seg_cnt, (size_t)(B * BK_THREADS) * sizeof(int32_t)));
+        }
         HIPCHK(h, dev_alloc((void**)&h->d_cur, (size_t)(B * SDR_CUR_CAP) * sizeof(double)));
         HIPCHK(h, dev_alloc((void**)&h->d_st, (size_t)B * sizeof(DecState)));
         HIPCHK(h, hipMemset(h->d_st, 0, (size_t)B * sizeof(DecState)));
@@ -946,7 +953,26 @@ static int launch_back(sdr_handle* h, int ncap, const CallGeom& g, long long pat
     Bp.max_frames = c.max_frames;
     Bp.pow_m13 = h->d_pow;
     Bp.log2n = h->d_log2;
-    hipLaunchKernelGGL(k_backend, dim3(ncap), dim3(BK_THREADS), 0, h->stream, Bp);
+    if (h->d_runs_seg && !Bp.nout_var && run_decoder && c.decoder != SDR_DEC_NONE && nb_total >= SDR_SEG_MIN_ROW &&
+        !getenv("SDR_NO_SEG")) {
+        // long rows: carries first (they patch the bytes), then the run starts of every 64-KiB-or-more
+        // segment by its own workgroup, then the decoders on the gathered run table
+        const long long round = BK_THREADS * 64;
+        long long seg = 4 * round;
+        if ((nb_total + seg - 1) / seg > BK_THREADS) seg = ((nb_total + BK_THREADS - 1) / BK_THREADS + round - 1) / round * round;
+        Bp.seg_bytes = seg;
+        Bp.nseg = (int)((nb_total + seg - 1) / seg);
+        Bp.runs_seg = h->d_runs_seg;
+        Bp.seg_cnt = h->d_seg_cnt;
+        Bp.phase_sel = 1;
+        hipLaunchKernelGGL(k_backend, dim3(ncap), dim3(BK_THREADS), 0, h->stream, Bp);
+        hipLaunchKernelGGL(k_runs_seg, dim3(Bp.nseg, ncap), dim3(BK_THREADS), 0, h->stream, Bp);
+        Bp.phase_sel = 2;
+        Bp.tsum = nullptr;
+        Bp.fresh = 0;
+        hipLaunchKernelGGL(k_backend, dim3(ncap), dim3(BK_THREADS), 0, h->stream, Bp);
+    } else
+        hipLaunchKernelGGL(k_backend, dim3(ncap), dim3(BK_THREADS), 0, h->stream, Bp);
     HIPCHK(h, hipGetLastError());
     if (h->profile) {
         HIPCHK(h, hipEventRecord(h->pev[3 * (h->pcount % SDR_PROF_RING) + 2], h->stream));

@@ -481,3 +481,55 @@ def test_tfa_fsk_discriminator_chain():
         else:
             assert_tfa_equal(of, gf)
     assert [f.packet() for f in frames if f.status == 0] == pkts
+
+
+@pytest.mark.parametrize("extra", [0, 1, 15, 16383, 16384, 70001])
+def test_long_row_segment_parallel_run_length(extra, monkeypatch):
+    """Rows of 128 KiB and more: k_backend resolves the carries, k_runs_seg finds the run starts of
+    every segment with its own workgroup, k_backend gathers and decodes.  Same frames as the
+    single-workgroup pass (SDR_NO_SEG=1) and as the oracle decoder, also when the row ends inside a
+    round or exactly on a segment boundary, and through the whole chain (carry patch first)."""
+    rate = 2000000
+    rng = np.random.default_rng(77)
+    pkts, sym = [], []
+    for _ in range(14):
+        p = synth.tfa_packet(ident=int(rng.integers(0, 65536)), temp_c=float(rng.integers(-300, 500)) / 10,
+                             humidity=int(rng.integers(0, 100)), battery_ok=bool(rng.integers(0, 2)))
+        pkts.append(p)
+        sym += synth.tfa_symbols(synth.tfa_bits(p), rng, reset_gap_us=4000.0)
+    env = synth.envelope(sym, rate, lead_in_us=900.0)
+    n = 4 * 65536 + extra
+    assert env.size + 1500 < n
+    env = np.concatenate([env, np.zeros(n - env.size, np.uint8)]).astype(np.int8)
+    o = odec.TFAStreamDecoder(sample_rate=rate)
+    o.work([env])
+    got = {}
+    for mode in ("seg", "single"):
+        if mode == "single":
+            monkeypatch.setenv("SDR_NO_SEG", "1")
+        with chain.Chain(rate, decoder=chain.DEC_TFA, decoder_rate=rate, max_samples=env.size, max_frames=32) as c:
+            c.process_bits(env)
+            got[mode] = [_copy(f) for f in c.fetch_frames()]
+            state = c.decoder_state()
+        assert state == [int(o.state == "frame"), int(o.currentSymbols.size), int(o.previousSymbolType), o.chunk_id]
+        assert len(got[mode]) == len(o.frames) == 14
+        for of, gf, p in zip(o.frames, got[mode], pkts):
+            assert_tfa_equal(of, gf)
+            assert gf.packet() == p
+    monkeypatch.delenv("SDR_NO_SEG")
+    # the same row through the whole OOK chain: the hysteresis carries are patched by the first launch
+    iq = synth.ook_iq(env.astype(np.uint8), rate, f_off=0.0, amp=0.9, sigma=0.01, rng=rng)
+    taps = chain.low_pass(1.0, rate, 500e3, 1e6, chain.WIN_BLACKMAN)
+    with chain.Chain(rate, decim=1, taps=taps, thr=(0.2, 0.4), decoder=chain.DEC_TFA_GRC, max_samples=iq.size,
+                     max_frames=32) as c:
+        c.batch_process(iq[None, :])
+        bits = c.fetch_bits()
+        frames = [_copy(f) for f in c.fetch_frames()]
+    wb = odsp.ook_chain(iq, taps, 1, 1.0, 0.2, 0.4, 1)
+    assert np.array_equal(bits, wb)
+    o2 = odec.TFAStreamDecoder(sample_rate=rate, nan_guard=True)
+    o2.work([wb])
+    assert len(frames) == len(o2.frames)
+    for of, gf in zip(o2.frames, frames):
+        assert_tfa_equal(of, gf)
+    assert [f.packet() for f in frames if f.status == 0] == pkts
