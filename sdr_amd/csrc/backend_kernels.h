@@ -321,6 +321,32 @@ struct EdgeReader {
     }
 };
 
+// bits[0..n) (one 0/1 byte each, n <= 64) -> bytes, first bit = MSB of out[0] (np.packbits).  Built in
+// registers and stored once: OR-ing bit by bit into the frame record in HBM is a dependent global
+// read-modify-write per bit (32 of them were 2/3 of the berner back end).  On the device, when the whole
+// wavefront runs the rule, lane i looks at bit i and one ballot gives the packed word.
+SDR_HD inline void pack_bits_msb(const EdgeCtx& e, const unsigned char* bits, int n, unsigned char* out)
+{
+    const int nby = (n + 7) >> 3;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (e.wave) {
+        const int lane = (int)(threadIdx.x & 63);
+        const unsigned long long m = __ballot(lane < n && bits[lane] != 0);
+        for (int j = 0; j < nby; ++j) out[j] = __builtin_bitreverse8((unsigned char)((m >> (8 * j)) & 0xffu));
+        return;
+    }
+#endif
+    for (int j = 0; j < nby; ++j) out[j] = 0;
+    for (int i = 0; i < n; ++i)
+        if (bits[i]) out[i >> 3] |= (unsigned char)(0x80u >> (i & 7));
+}
+
+// Differences of ticks are never negative (ticks ascend) and every limit they are compared with is far
+// below 2^31: clamped to INT_MAX they compare exactly as the 64-bit values would, and the rule's tests
+// become 32-bit scalar compares (gfx950 has no 64-bit scalar ordering compare: each 64-bit in_range was
+// a VALU compare feeding a scalar branch).
+SDR_HD inline int sat_delta(long long d) { return d > 0x7fffffffLL ? 0x7fffffff : (int)d; }
+SDR_HD inline bool in_range(int d, int a, int b) { return d >= a && d < b; }
 SDR_HD inline bool in_range(long long d, long long a, long long b) { return d >= a && d < b; }
 
 SDR_HD inline sdr_frame* next_frame(const BackParams& P, DecState* st, int cap, long long end_pos)
@@ -343,7 +369,7 @@ SDR_HD inline void rule_somfy(const EdgeCtx& e, const BackParams& P, DecState* s
     long long start_tick = 0;
     int state = 0, nbits = 0, clock = 640, n_sync = 0;
     double sync_sum = 0.0;  // np.average of <8 values: sequential sum
-    const long long wd = 20000;
+    const int wd = 20000;
     long long prev_tick = 0;
     auto watchdog = [&](long long at_run) {
         if (state > 0) {
@@ -383,7 +409,7 @@ SDR_HD inline void rule_somfy(const EdgeCtx& e, const BackParams& P, DecState* s
             if (nbits < 512) bits[nbits++] = (unsigned char)v;
     };
     auto event = [&](int level, long long tick) {
-        long long delta = tick - start_tick;
+        const int delta = sat_delta(tick - start_tick);
         start_tick = tick;
         if (level == 1) {  // end of gap
             if (state <= 2 && in_range(delta, 2500 - 2 * tol, 2500 + 2 * tol)) {
@@ -425,13 +451,13 @@ SDR_HD inline void rule_somfy(const EdgeCtx& e, const BackParams& P, DecState* s
     for (long long k = 1; k < e.R; ++k) {
         long long tick, at;
         rd.get(k, tick, at);
-        if (tick - prev_tick > wd) watchdog(at);
+        if (sat_delta(tick - prev_tick) > wd) watchdog(at);
         level ^= 1;
         event(level, tick);
         prev_tick = tick;
     }
     long long end_tick = (e.nb * 1000000LL) / e.rate_hz;
-    if (end_tick - prev_tick > wd) watchdog(e.nb);
+    if (sat_delta(end_tick - prev_tick) > wd) watchdog(e.nb);
 }
 
 // berner/sniff.py:21-44
@@ -445,7 +471,7 @@ SDR_HD inline void rule_berner(const EdgeCtx& e, const BackParams& P, DecState* 
         if (lvl == 1)
             start_tick = tick;
         else {
-            long long delta = tick - start_tick;
+            const int delta = sat_delta(tick - start_tick);
             if (state == 0 && delta > 5300 && delta < 5700) {
                 nbits = 0;
                 state = 1;
@@ -457,8 +483,9 @@ SDR_HD inline void rule_berner(const EdgeCtx& e, const BackParams& P, DecState* 
                 if (nbits >= 32) {
                     sdr_frame* f = next_frame(P, st, cap, at);
                     if (f) {
-                        for (int i = 0; i < 32; ++i)
-                            if (bits[i]) f->bytes[i >> 3] |= (unsigned char)(0x80u >> (i & 7));
+                        unsigned char by[4];
+                        pack_bits_msb(e, bits, 32, by);
+                        for (int j = 0; j < 4; ++j) f->bytes[j] = by[j];
                         f->nbits = nbits;
                         f->nbytes = 4;
                         f->status = SDR_FRAME_OK;
@@ -483,7 +510,7 @@ SDR_HD inline void rule_mumbi(const EdgeCtx& e, const BackParams& P, DecState* s
                                   unsigned char* bits)
 {
     const int tol = 50;
-    const long long wd = 8000;
+    const int wd = 8000;
     long long start_tick = 0, prev_tick = 0;
     int state = 0, nbits = 0;
     int level = e.first_level;
@@ -492,8 +519,9 @@ SDR_HD inline void rule_mumbi(const EdgeCtx& e, const BackParams& P, DecState* s
             if (nbits == 34) {
                 sdr_frame* f = next_frame(P, st, cap, at);
                 if (f) {
-                    for (int i = 0; i < 34; ++i)
-                        if (bits[i]) f->bytes[i >> 3] |= (unsigned char)(0x80u >> (i & 7));
+                    unsigned char by[5];
+                    pack_bits_msb(e, bits, 34, by);
+                    for (int j = 0; j < 5; ++j) f->bytes[j] = by[j];
                     f->nbits = 34;
                     f->nbytes = 5;
                     f->status = SDR_FRAME_OK;
@@ -507,7 +535,7 @@ SDR_HD inline void rule_mumbi(const EdgeCtx& e, const BackParams& P, DecState* s
         if (lvl == 1)
             start_tick = tick;
         else {
-            long long delta = tick - start_tick;
+            const int delta = sat_delta(tick - start_tick);
             if (in_range(delta, 820 - 2 * tol, 820 + 2 * tol)) {
                 if (nbits < 512) bits[nbits++] = 1;
                 state = 1;
@@ -521,13 +549,13 @@ SDR_HD inline void rule_mumbi(const EdgeCtx& e, const BackParams& P, DecState* s
     for (long long k = 1; k < e.R; ++k) {
         long long tick, at;
         rd.get(k, tick, at);
-        if (tick - prev_tick > wd) watchdog(at);
+        if (sat_delta(tick - prev_tick) > wd) watchdog(at);
         level ^= 1;
         event(level, tick);
         prev_tick = tick;
     }
     long long end_tick = (e.nb * 1000000LL) / e.rate_hz;
-    if (end_tick - prev_tick > wd) watchdog(e.nb);
+    if (sat_delta(end_tick - prev_tick) > wd) watchdog(e.nb);
 }
 
 // kwmobile/decoder.py:95-135 (Nexus-type PPM sensor; watchdog 3 ms, :145).  Only the
@@ -536,7 +564,7 @@ SDR_HD inline void rule_kwmobile(const EdgeCtx& e, const BackParams& P, DecState
                                  unsigned char* bits)
 {
     const int tol = 50;
-    const long long wd = 3000;
+    const int wd = 3000;
     long long start_tick = 0, prev_tick = 0;
     int state = 0, nbits = 0;
     int level = e.first_level;
@@ -545,9 +573,9 @@ SDR_HD inline void rule_kwmobile(const EdgeCtx& e, const BackParams& P, DecState
             if (nbits == 36) {
                 sdr_frame* f = next_frame(P, st, cap, at);
                 if (f) {
-                    for (int i = 0; i < 36; ++i)
-                        if (bits[i]) f->bytes[i >> 3] |= (unsigned char)(0x80u >> (i & 7));
-                    const unsigned char* b = f->bytes;
+                    unsigned char b[5];
+                    pack_bits_msb(e, bits, 36, b);
+                    for (int j = 0; j < 5; ++j) f->bytes[j] = b[j];
                     f->nbits = 36;
                     f->nbytes = 5;
                     f->temp_tenths = ((b[1] & 0x0f) << 8) | b[2];
@@ -564,7 +592,7 @@ SDR_HD inline void rule_kwmobile(const EdgeCtx& e, const BackParams& P, DecState
     };
     auto event = [&](int lvl, long long tick) {
         if (lvl != 1) return;
-        long long delta = tick - start_tick;
+        const int delta = sat_delta(tick - start_tick);
         start_tick = tick;
         if (state == 0 && in_range(delta, 4500 - 4 * tol, 4500 + 4 * tol))
             state = 1;
@@ -579,13 +607,13 @@ SDR_HD inline void rule_kwmobile(const EdgeCtx& e, const BackParams& P, DecState
     for (long long k = 1; k < e.R; ++k) {
         long long tick, at;
         rd.get(k, tick, at);
-        if (tick - prev_tick > wd) watchdog(at);
+        if (sat_delta(tick - prev_tick) > wd) watchdog(at);
         level ^= 1;
         event(level, tick);
         prev_tick = tick;
     }
     long long end_tick = (e.nb * 1000000LL) / e.rate_hz;
-    if (end_tick - prev_tick > wd) watchdog(e.nb);
+    if (sat_delta(end_tick - prev_tick) > wd) watchdog(e.nb);
 }
 
 // baldr/decoder.py:87-142 (watchdog 18 ms, :152): one decode per transmission, of the
@@ -594,8 +622,8 @@ SDR_HD inline void rule_baldr(const EdgeCtx& e, const BackParams& P, DecState* s
                               unsigned char* bits)
 {
     const int tol = 200;
-    const long long wd = 18000;
-    const long long medium = 2650, lng = 4700, verylong = 9600;
+    const int wd = 18000;
+    const int medium = 2650, lng = 4700, verylong = 9600;
     long long start_tick = 0, prev_tick = 0;
     int state = 0, nbits = 0;
     int level = e.first_level;
@@ -604,9 +632,9 @@ SDR_HD inline void rule_baldr(const EdgeCtx& e, const BackParams& P, DecState* s
             if (nbits == 37) {
                 sdr_frame* f = next_frame(P, st, cap, at);
                 if (f) {
-                    for (int i = 0; i < 37; ++i)
-                        if (bits[i]) f->bytes[i >> 3] |= (unsigned char)(0x80u >> (i & 7));
-                    const unsigned char* b = f->bytes;
+                    unsigned char b[5];
+                    pack_bits_msb(e, bits, 37, b);
+                    for (int j = 0; j < 5; ++j) f->bytes[j] = b[j];
                     f->nbits = 37;
                     f->nbytes = 5;
                     int t = ((int)b[2] << 4) | (b[3] >> 4);
@@ -625,7 +653,7 @@ SDR_HD inline void rule_baldr(const EdgeCtx& e, const BackParams& P, DecState* s
     };
     auto event = [&](int lvl, long long tick) {
         if (lvl != 1) return;
-        long long delta = tick - start_tick;
+        const int delta = sat_delta(tick - start_tick);
         start_tick = tick;
         if (state == 0 && in_range(delta, verylong - tol, verylong + tol))
             state = 1;
@@ -647,13 +675,13 @@ SDR_HD inline void rule_baldr(const EdgeCtx& e, const BackParams& P, DecState* s
     for (long long k = 1; k < e.R; ++k) {
         long long tick, at;
         rd.get(k, tick, at);
-        if (tick - prev_tick > wd) watchdog(at);
+        if (sat_delta(tick - prev_tick) > wd) watchdog(at);
         level ^= 1;
         event(level, tick);
         prev_tick = tick;
     }
     long long end_tick = (e.nb * 1000000LL) / e.rate_hz;
-    if (end_tick - prev_tick > wd) watchdog(e.nb);
+    if (sat_delta(end_tick - prev_tick) > wd) watchdog(e.nb);
 }
 
 // velux/decoder.py:30-101 (io-homecontrol): the sliced stream is one byte per symbol.
