@@ -226,9 +226,9 @@ def cu8_workload(torch, dev, iq, pkts, taps, steps=20):
     c.close()
     return {"value": round(ncap * n / dt / 1e6, 1), "unit": "Msps", "ms_per_step": round(dt * 1e3, 4),
             "captures": ncap, "samples_per_capture": n, "input": "cu8 (u8 I, u8 Q), (x-127.4)/128 while staging",
-            "roofline": {"bound": "hbm", "kernel": "k_frontend_pipe<true, 8>", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "k_frontend_raw8", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                         "traffic": pmc_traffic("k_frontend_pipe<true, 8> cu8", "captures_per_gpu=%d" % ncap)[0],
+                         "traffic": pmc_traffic("k_frontend_raw8 cu8", "captures_per_gpu=%d" % ncap)[0],
                          "kernel_ms": round(fk, 4), "backend_kernel_ms": round(float(np.mean(back_ms)), 4),
                          "bytes_per_launch": bps * ncap * n,
                          "note": "2.02 algorithmic bytes per sample: the kernel is latency/issue bound, not HBM "

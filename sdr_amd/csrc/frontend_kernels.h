@@ -140,6 +140,42 @@ __device__ __forceinline__ void slice_tile(bool valid, float v, long long o, lon
     }
 }
 
+// Everything behind the channel filter for thread t's output o = (ar, ai): demodulator, gain,
+// optional tap, hysteresis scan + slicer.  SYNC_TILE: ysh aliases the LDS tile, so every wave must
+// have finished reading it before the discriminator exchange overwrites it.
+template <bool SYNC_TILE>
+__device__ __forceinline__ void frontend_finish(const FrontParams& P, const int tile, const int cap, const int t,
+                                                const int q, const long long o, const float ar, const float ai,
+                                                float2* ysh, int* sh)
+{
+    bool valid = (t >= q) && (o < P.nout) && (t - q < P.tile_out);
+    float v = 0.f;
+    if (P.demod == SDR_DEMOD_NONE) {
+        if (valid && P.tap)
+            reinterpret_cast<float2*>(P.tap + (long long)cap * P.tap_stride)[o] = make_float2(ar, ai);
+        return;
+    } else if (P.demod == SDR_DEMOD_MAG2) {
+        v = __builtin_fmaf(ar, ar, ai * ai);
+    } else {
+        if (SYNC_TILE) __syncthreads();  // every wave has finished reading the tile
+        ysh[t] = make_float2(ar, ai);
+        __syncthreads();
+        if (valid) {
+            float2 pv = ysh[t - 1];
+            float tr = __builtin_fmaf(ar, pv.x, ai * pv.y);
+            float ti = __builtin_fmaf(ai, pv.x, -(ar * pv.y));
+            v = fast_atan2f_dev(P.atan_tab, ti, tr);
+        }
+    }
+    v = P.gain * v;
+    if (valid && P.tap) (P.tap + (long long)cap * P.tap_stride)[o] = v;
+    if (!P.do_slice) return;
+    // slice_tile wants the output index of thread 0 (= o0 - q)
+    slice_tile(valid, v, o, o - t, P.lo, P.hi, P.keep_n, P.keep_c0,
+               P.bits + (long long)cap * P.bits_stride,
+               P.tsum + (long long)cap * P.tiles_per_capture + tile, sh);
+}
+
 // One thread = one FIR output.  Tile = blockDim.x consecutive FIR outputs whose
 // (T-1)*D + ntaps input samples are staged once in LDS (coalesced 8-B loads),
 // then every thread walks its ntaps-window with ds_read_b64 + 2 (4) fmaf.
@@ -400,32 +436,7 @@ __device__ __forceinline__ void frontend_tile(const FrontParams& P, const FrontK
         }
     }
 
-    bool valid = (t >= q) && (o < P.nout) && (t - q < P.tile_out);
-    float v = 0.f;
-    if (P.demod == SDR_DEMOD_NONE) {
-        if (valid && P.tap)
-            reinterpret_cast<float2*>(P.tap + (long long)cap * P.tap_stride)[o] = make_float2(ar, ai);
-        return;
-    } else if (P.demod == SDR_DEMOD_MAG2) {
-        v = __builtin_fmaf(ar, ar, ai * ai);
-    } else {
-        if (USE_LDS) __syncthreads();  // every wave has finished reading the tile
-        ysh[t] = make_float2(ar, ai);
-        __syncthreads();
-        if (valid) {
-            float2 pv = ysh[t - 1];
-            float tr = __builtin_fmaf(ar, pv.x, ai * pv.y);
-            float ti = __builtin_fmaf(ai, pv.x, -(ar * pv.y));
-            v = fast_atan2f_dev(P.atan_tab, ti, tr);
-        }
-    }
-    v = P.gain * v;
-    if (valid && P.tap) (P.tap + (long long)cap * P.tap_stride)[o] = v;
-    if (!P.do_slice) return;
-    // slice_tile wants the output index of thread 0 (= o0 - q)
-    slice_tile(valid, v, o, o - t, P.lo, P.hi, P.keep_n, P.keep_c0,
-               P.bits + (long long)cap * P.bits_stride,
-               P.tsum + (long long)cap * P.tiles_per_capture + tile, sh);
+    frontend_finish<USE_LDS>(P, tile, cap, t, q, o, ar, ai, ysh, sh);
 }
 
 // CU8 = the input is rtl-sdr bytes (sdr_set_input_format).  Aligned cu8 batches and calls
@@ -439,6 +450,114 @@ __global__ void __launch_bounds__(256) k_frontend(FrontParams P, FrontKTaps KT)
     // discriminator history exchange: aliases the (by then consumed) tile when there is one
     __shared__ float2 ysh_static[USE_LDS ? 1 : 256];
     frontend_tile<USE_LDS, CU8>(P, KT, blockIdx.x, blockIdx.y, reinterpret_cast<float2*>(smem_raw), sh, ysh_static);
+}
+
+// Tap loop of k_frontend_raw8: samples are (I, Q) byte pairs in LDS, converted as they are read.
+template <bool CPLX>
+__device__ __forceinline__ void raw8_fir(const FrontKTaps& KT, const unsigned short* pu, const int nt, const bool edge,
+                                         const long long s0, const long long vlo, const long long n, float& ar, float& ai)
+{
+    const float kS = 0.0078125f, kC = -127.4f * 0.0078125f;
+    auto mac = [&](unsigned r, bool ok, int j) {
+        float sx = __builtin_fmaf((float)(r & 0xffu), kS, kC);
+        float sy = __builtin_fmaf((float)(r >> 8), kS, kC);
+        if (!ok) sx = sy = 0.f;
+        const float a = KT.t[j].x, b = KT.t[j].y;
+        ar = __builtin_fmaf(a, sx, ar);
+        if (CPLX) ar = __builtin_fmaf(-b, sy, ar);
+        ai = __builtin_fmaf(a, sy, ai);
+        if (CPLX) ai = __builtin_fmaf(b, sx, ai);
+    };
+    int j = 0;
+    if (!edge) {
+        for (; j + 8 <= nt; j += 8) {
+            unsigned r[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) r[u] = pu[j + u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) mac(r[u], true, j + u);
+        }
+    }
+    for (; j < nt; ++j) {
+        const long long idx = s0 + j;
+        mac(pu[j], !edge || (idx >= vlo && idx < n), j);
+    }
+}
+
+// rtl-sdr bytes kept as bytes: the tile is staged by the same 16-B direct-to-LDS DMA as the complex64
+// kernel, but as the raw (I, Q) byte pairs -- 2 B per sample, a quarter of the float tile, so four times
+// as many workgroups fit a CU -- and every lane converts its window's samples ((u - 127.4)/128, the two
+// exact float ops of the oracle) on the way from LDS into the fmas.  With 61 taps at decimation 50 a
+// sample is used 1.2 times, so converting at the read costs what converting at the staging did.
+// Zero padding (capture edges without history) cannot be written as a byte: edge tiles (wave-uniform
+// test) mask the samples outside [first valid, n) in the tap loop instead.  Needs the taps in the
+// kernel arguments (<= 64), a 16-B aligned buffer and no pre-rotation; other cu8 calls take
+// k_frontend_pipe / k_frontend<., true>.
+__global__ void __launch_bounds__(256) k_frontend_raw8(FrontParams P, FrontKTaps KT)
+{
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    __shared__ int sh[12];
+    __shared__ float2 ysh[256];
+    const int T = blockDim.x, t = threadIdx.x, tile = blockIdx.x, cap = blockIdx.y;
+    const int q = (P.demod == SDR_DEMOD_QUAD) ? 1 : 0;
+    const int H = P.ntaps - 1;
+    const int count = (T - 1) * P.D + P.ntaps;
+    const long long m_t0 = (long long)tile * P.tile_out - q;
+    const long long lo_idx = P.in0 + m_t0 * P.D - H;                       // first input sample of the tile
+    const int off = (int)(((long long)cap * P.stride + lo_idx) & 7);       // 8 samples = one 16-B chunk
+    const long long lo = lo_idx - off;
+    const int nch = (count + off + 7) >> 3;
+    const uchar2* __restrict__ xb = reinterpret_cast<const uchar2*>(P.x) + (long long)cap * P.stride;
+    const long long vlo = P.hist ? -(long long)P.hist_len : 0;             // first sample that exists
+    uchar2* lds2 = reinterpret_cast<uchar2*>(smem_raw);
+
+    // chunks wholly inside the capture: DMA, nothing else in the loop
+    for (int c0 = (t & ~63); c0 < nch; c0 += T) {
+        const int c = c0 + lane_id();
+        const long long s = lo + 8LL * c;
+        if (c < nch && s >= 0 && s + 8 <= P.n)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xb + s),
+                                             (__attribute__((address_space(3))) void*)(smem_raw + 16 * c0), 16, 0,
+                                             SDR_GLDS_AUX);
+    }
+    const bool edge = lo < 0 || lo + 8LL * nch > P.n;                      // uniform
+    if (edge) {
+        for (int c = t; c < nch; c += T) {
+            const long long s = lo + 8LL * c;
+            if (!(s >= 0 && s + 8 <= P.n))
+                for (int j = 0; j < 8; ++j) {
+                    const long long idx = s + j;
+                    uchar2 u = make_uchar2(0, 0);
+                    if (idx >= 0) {
+                        if (idx < P.n) u = xb[idx];
+                    } else if (idx >= vlo)
+                        u = reinterpret_cast<const uchar2*>(P.hist)[P.hist_len + idx];
+                    lds2[8 * c + j] = u;
+                }
+        }
+    }
+    __syncthreads();
+
+    const long long m = m_t0 + t;
+    const bool have_y = (m >= 0 || P.hist != nullptr) && (m < P.nout);
+    float ar = 0.f, ai = 0.f;
+    {
+        const unsigned short* pu = reinterpret_cast<const unsigned short*>(smem_raw) + off + t * P.D;
+        const long long s0 = lo_idx + (long long)t * P.D;                  // sample index of tap 0
+        if (P.taps_complex)
+            raw8_fir<true>(KT, pu, P.ntaps, edge, s0, vlo, P.n, ar, ai);
+        else
+            raw8_fir<false>(KT, pu, P.ntaps, edge, s0, vlo, P.n, ar, ai);
+        if (!have_y) ar = ai = 0.f;
+    }
+    if (have_y && P.nco_tab) {
+        const float2 r = nco_eval(P.nco_tab, (P.nco_m0 + (unsigned long long)m) * P.nco_inc);
+        const float yr = __builtin_fmaf(ar, r.x, -(ai * r.y));
+        const float yi = __builtin_fmaf(ar, r.y, ai * r.x);
+        ar = yr;
+        ai = yi;
+    }
+    frontend_finish<false>(P, tile, cap, t, q, m, ar, ai, ysh, sh);
 }
 
 // Register-staged form, the default for cu8 input: the tile's bytes come in as plain

@@ -784,7 +784,12 @@ static int launch_front(sdr_handle* h, const float2* x, long long stride, long l
     dim3 grid(g.tiles, ncap), block(g.T);
     if (g.mfma)
         hipLaunchKernelGGL(k_frontend_mfma, grid, block, g.lds, h->stream, P);
-    else if (g.pipe_nch && P.vec_ok && !P.pre_tab) {
+    else if (h->in_fmt == SDR_IN_CU8 && P.vec_ok && !P.pre_tab && P.ktaps_n > 0 && g.use_lds && !getenv("SDR_NO_RAW8")) {
+        // bytes stay bytes in LDS: (count + up to 7 samples of alignment) rounded up to 16-B chunks
+        const long long count = (long long)(g.T - 1) * c.decim + h->ntaps;
+        const size_t lds = (size_t)((count + 7 + 7) / 8) * 16;
+        hipLaunchKernelGGL(k_frontend_raw8, grid, block, lds, h->stream, P, h->ktaps);
+    } else if (g.pipe_nch && P.vec_ok && !P.pre_tab) {
         dim3 pgrid((g.tiles + g.pipe_tpw - 1) / g.pipe_tpw, ncap);
         const bool cu8 = h->in_fmt == SDR_IN_CU8;
 #define SDR_PIPE_LAUNCH(C, N) hipLaunchKernelGGL((k_frontend_pipe<C, N>), pgrid, block, g.lds, h->stream, P, h->ktaps, g.pipe_tpw)
