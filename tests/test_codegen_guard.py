@@ -15,6 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KERNELS = {
     "_Z10k_frontendILb1ELb0EEv11FrontParams10FrontKTaps": "k_frontend<true,false>",
     "_Z15k_frontend_mfma11FrontParams": "k_frontend_mfma",
+    "_Z15k_frontend_raw811FrontParams10FrontKTaps": "k_frontend_raw8",
     "_Z5k_pfbILi8EEv9PfbParams": "k_pfb<8>",
 }
 
