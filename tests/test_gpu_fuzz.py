@@ -28,3 +28,13 @@ def test_random_symbol_streams_decode_like_the_oracle():
     rng = np.random.default_rng(4048)
     fails = [r for r in (fuzz_decode.one(rng, k) for k in range(150)) if r]
     assert not fails, fails[:5]
+
+
+def test_random_emitter_streams_through_every_rule_decoder():
+    """tools/fuzz_rules.py: somfy / berner / mumbi / kwmobile / baldr transmissions with junk, gaps and cut
+    repeats, every stream through all five rule decoders; frames equal the oracle sniffers'."""
+    import fuzz_rules
+    rng = np.random.default_rng(515)
+    fails = [r for r in (fuzz_rules.one(rng, k) for k in range(120)) if r]
+    assert not fails, fails[:5]
+    assert fuzz_rules.NFRAMES[0] > 100
