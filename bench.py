@@ -548,7 +548,10 @@ def main():
         raise SystemExit("bench.py needs a GPU (no CPU path)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    # SDR_BENCH_DIST=1 under torchrun with ONE rank walks the multi-GPU code (RCCL init, frame gather,
+    # barriers, max over ranks) on a one-GPU box
+    use_dist = world > 1 or (os.environ.get("SDR_BENCH_DIST") == "1" and "MASTER_ADDR" in os.environ)
+    if use_dist:
         dist.init_process_group("nccl", device_id=dev)
 
     ncap = args.captures
@@ -560,20 +563,37 @@ def main():
     c.set_stream(torch.cuda.current_stream().cuda_stream)
     rec = torch.zeros(ncap * max_frames * 96, dtype=torch.uint8, device=dev)
     cnt = torch.zeros(ncap, dtype=torch.int32, device=dev)
-    if world > 1:
-        all_rec = torch.zeros(world * rec.numel(), dtype=torch.uint8, device=dev)
-        all_cnt = torch.zeros(world * ncap, dtype=torch.int32, device=dev)
+    if use_dist:
+        # The frame gather of step k runs on its own stream while the front end of step k+1 runs on the
+        # main one: frame records are exported (a small copy kernel on the main stream) into one of two
+        # buffer pairs, the RCCL all_gather of that pair is queued behind an event on the side stream,
+        # and a pair is reused only after its gather has finished.
+        comm = torch.cuda.Stream(device=dev)
+        recs, cnts = [rec, torch.zeros_like(rec)], [cnt, torch.zeros_like(cnt)]
+        all_recs = [torch.zeros(world * rec.numel(), dtype=torch.uint8, device=dev) for _ in range(2)]
+        all_cnts = [torch.zeros(world * ncap, dtype=torch.int32, device=dev) for _ in range(2)]
+        ev_exported = [torch.cuda.Event() for _ in range(2)]
+        ev_gathered = [torch.cuda.Event() for _ in range(2)]
+    kstep = [0]
 
     def step():
         c.batch_process(iq)
-        if world > 1:
-            c.export_frames(rec, cnt)
-            sdist.gather_frames(rec, cnt, world, all_rec, all_cnt)
+        if use_dist:
+            b = kstep[0] & 1
+            kstep[0] += 1
+            main_stream = torch.cuda.current_stream()
+            main_stream.wait_event(ev_gathered[b])
+            c.export_frames(recs[b], cnts[b])
+            ev_exported[b].record(main_stream)
+            with torch.cuda.stream(comm):
+                comm.wait_event(ev_exported[b])
+                sdist.gather_frames(recs[b], cnts[b], world, all_recs[b], all_cnts[b])
+                ev_gathered[b].record(comm)
 
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     c.profile_enable(True)
@@ -581,17 +601,25 @@ def main():
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     front_ms, back_ms = c.profile_read()
     c.profile_enable(False)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    if use_dist:
+        # what the last step gathered: every rank's counts and records, this rank's own slice intact
+        b = (kstep[0] - 1) & 1
+        if int(all_cnts[b].sum().item()) != 2 * ncap * world:
+            raise SystemExit("rank %d: gathered frame counts sum to %d, expected %d" % (rank, int(all_cnts[b].sum().item()), 2 * ncap * world))
+        mine = all_recs[b][rank * rec.numel():(rank + 1) * rec.numel()]
+        if not bool(torch.equal(mine, recs[b])) or not bool(torch.equal(all_cnts[b][rank * ncap:(rank + 1) * ncap], cnts[b])):
+            raise SystemExit("rank %d: own slice of the gathered frame table differs" % rank)
     # ---- correctness of what was timed (size-independent property + oracle spot check)
     frames = c.fetch_frames()
     got = {}
@@ -658,7 +686,7 @@ def main():
             line["other_workloads"] = other
         print(json.dumps(line))
     c.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
