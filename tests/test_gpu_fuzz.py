@@ -38,3 +38,12 @@ def test_random_emitter_streams_through_every_rule_decoder():
     fails = [r for r in (fuzz_rules.one(rng, k) for k in range(120)) if r]
     assert not fails, fails[:5]
     assert fuzz_rules.NFRAMES[0] > 100
+
+
+def test_random_channelizer_shapes_match_the_oracle():
+    """tools/fuzz_pfb.py: prototype filters of 1 to 1024 taps, captures from less than one frame of 64
+    samples to thousands, batches, keep_n: channel floats and sliced bytes bit-identical to the oracle."""
+    import fuzz_pfb
+    rng = np.random.default_rng(64)
+    fails = [r for r in (fuzz_pfb.one(rng, k) for k in range(60)) if r]
+    assert not fails, fails[:5]
