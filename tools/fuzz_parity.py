@@ -13,6 +13,37 @@ FS = 1e6
 TOTAL = [0, 0]
 
 
+def special(rng, k, raw, z, taps, D, fc, cplx, quad, keep, n, ncap, lo, hi, gain, sq, post):
+    desc = "case %d: fc32 D=%d ntaps=%d %s %s keep=%d n=%d ncap=%d squelch=%s post=%s" % (
+        k, D, taps.size, "xlating" if cplx else "real", "quad" if quad else "mag2", keep, n, ncap, sq,
+        None if post is None else post.size)
+    x = raw.view(np.complex64).reshape(ncap, n)
+    kw = dict(decim=D, center_freq=fc, taps=taps, demod=chain.DEMOD_QUAD if quad else chain.DEMOD_MAG2, demod_gain=gain,
+              thr=(lo, hi), keep_n=keep, max_samples=n, max_batch=ncap)
+    if sq:
+        kw["squelch"] = sq
+    else:
+        kw["post_taps"] = post
+    with chain.Chain(FS, **kw) as c:
+        c.batch_process(x)
+        b = c.fetch_bits().reshape(ncap, -1)
+        counts = c.fetch_squelch_counts() if sq else None
+    for i in range(ncap):
+        y = odsp.freq_xlating_fir(z[i], taps, fc, FS, D) if cplx else odsp.fir_ccf(z[i], taps, D)
+        if sq:
+            y = odsp.pwr_squelch(y, sq[0], sq[1], sq[2])
+            if int(counts[i]) != y.size:
+                return desc + " squelch count %d vs oracle %d" % (int(counts[i]), y.size)
+        v = odsp.quad_demod(y, gain) if quad else odsp.mag2(y)
+        if post is not None:
+            v = odsp.fir_fff(v, post, 1)
+        wb, _, _ = odsp.slice_bits(v, 1.0 if quad else gain, lo, hi, keep)
+        TOTAL[1] += wb.size
+        if not np.array_equal(b[i][:wb.size], wb):
+            return desc + " bits differ (capture %d)" % i
+    return None
+
+
 def one(rng, k):
     fmt = "cu8" if rng.random() < 0.5 else "fc32"
     D = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 10, 16, 25, 50, 64, 100]))
@@ -32,6 +63,16 @@ def one(rng, k):
         z = [raw[i].view(np.complex64).reshape(-1) for i in range(ncap)]
     lo, hi = (-0.3, 0.3) if quad else (0.2, 0.5)
     gain = np.float32(0.7)
+    # one in five chains carries a power squelch in front of the demodulator, one in five a float FIR
+    # behind mag^2 (TFA/decoder.grc and TFA/analyzer2.grc wirings); both bit-exact checks on the batch path
+    extra = rng.random()
+    sq = (float(rng.choice([-12.0, -6.0, 0.0])), float(rng.choice([1.0, 0.3, 0.01])), bool(rng.integers(0, 2))) \
+        if extra < 0.2 and fmt == "fc32" else None
+    post = (rng.standard_normal(int(rng.choice([1, 3, 7, 32]))) / 3).astype(np.float32) \
+        if 0.2 <= extra < 0.4 and not quad and fmt == "fc32" else None
+    if sq or post is not None:
+        keep = 1 if post is not None else keep
+        return special(rng, k, raw, z, taps, D, fc, cplx, quad, keep, n, ncap, lo, hi, gain, sq, post)
     desc = "case %d: %s D=%d ntaps=%d %s %s keep=%d n=%d ncap=%d" % (k, fmt, D, nt, "xlating" if cplx else "real",
                                                                     "quad" if quad else "mag2", keep, n, ncap)
     want_v, want_b = [], []
