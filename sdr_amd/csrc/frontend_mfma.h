@@ -115,6 +115,11 @@ __global__ void __launch_bounds__(256) k_frontend_mfma(FrontParams P)
 {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     __shared__ int sh[12];
+    // discriminator: the 257-entry arctangent table sits in LDS (two dependent lookups per output
+    // were two L1/L2 round trips each); filled here, first read after the barriers below
+    __shared__ float s_atan[257];
+    if (P.demod == SDR_DEMOD_QUAD)
+        for (int i = threadIdx.x; i < 257; i += blockDim.x) s_atan[i] = P.atan_tab[i];
     float* const ldsf = reinterpret_cast<float*>(smem_raw);
 
     const int T = blockDim.x, nw = T >> 6, TB = nw * 256;
@@ -292,7 +297,7 @@ __global__ void __launch_bounds__(256) k_frontend_mfma(FrontParams P)
                 const float2 pv = (e == 0) ? ybuf[4 * t - 1] : make_float2(ar[e - 1], ai[e - 1]);
                 const float tr = __builtin_fmaf(ar[e], pv.x, ai[e] * pv.y);
                 const float ti = __builtin_fmaf(ai[e], pv.x, -(ar[e] * pv.y));
-                v[e] = fast_atan2f_dev(P.atan_tab, ti, tr);
+                v[e] = fast_atan2f_dev(s_atan, ti, tr);
             }
         }
     }
