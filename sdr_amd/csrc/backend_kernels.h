@@ -461,10 +461,75 @@ SDR_HD inline void rule_somfy(const EdgeCtx& e, const BackParams& P, DecState* s
     if (sat_delta(end_tick - prev_tick) > wd) watchdog(e.nb);
 }
 
+#if defined(__HIP_DEVICE_COMPILE__)
+// berner rule, wavefront form: the pulse width of 64 falling edges at a time is classified one per
+// lane (preamble / "0" / "1" / other), the classes come back as ballot masks and the state machine
+// of berner/sniff.py:21-44 walks them with bit scans -- per frame, not per edge: from idle, the next
+// preamble; from there the run of "0"/"1" pulses up to the first pulse that is neither (which ends
+// the frame and is not looked at again, exactly as the sequential rule leaves it).
+__device__ inline void wave_rule_berner(const EdgeCtx& e, const BackParams& P, DecState* st, int cap)
+{
+    const int lane = (int)(threadIdx.x & 63);
+    const long long kf0 = e.first_level ? 1 : 2;   // first falling edge (pos[0] = 0 is the row start)
+    int state = 0, nbits = 0;
+    unsigned acc = 0;                              // first 32 bits, stream bit i at bit i
+    for (long long j0 = 0; kf0 + 2 * j0 < e.R; j0 += 64) {
+        const long long k = kf0 + 2 * (j0 + lane);
+        const bool in = k < e.R;
+        const int d = in ? sat_delta(tick_of(e, k) - tick_of(e, k - 1)) : 0;
+        const unsigned long long mIn = __ballot(in);
+        const unsigned long long mP = __ballot(in && d > 5300 && d < 5700);
+        const unsigned long long mO = __ballot(in && d > 500 && d < 1000);
+        const unsigned long long mZO = mO | __ballot(in && d < 500);
+        const int nin = __builtin_popcountll(mIn);
+        int cur = 0;
+        while (cur < nin) {
+            if (state == 0) {
+                const unsigned long long m = mP >> cur;
+                if (!m) break;
+                cur += __builtin_ctzll(m) + 1;
+                state = 1;
+                nbits = 0;
+                acc = 0;
+            } else {
+                const unsigned long long stop = (~mZO & mIn) >> cur;
+                const int run = stop ? __builtin_ctzll(stop) : nin - cur;
+                if (nbits < 32 && run > 0) {
+                    const int take = run < 32 - nbits ? run : 32 - nbits;
+                    const unsigned v = (unsigned)((mO >> cur) & ((1ull << take) - 1ull));
+                    acc |= v << nbits;
+                }
+                nbits = nbits + run > 512 ? 512 : nbits + run;
+                cur += run;
+                if (stop) {
+                    if (nbits >= 32) {
+                        sdr_frame* f = next_frame(P, st, cap, e.pos[kf0 + 2 * (j0 + cur)]);
+                        if (f) {
+                            for (int j = 0; j < 4; ++j) f->bytes[j] = __builtin_bitreverse8((unsigned char)((acc >> (8 * j)) & 0xffu));
+                            f->nbits = nbits;
+                            f->nbytes = 4;
+                            f->status = SDR_FRAME_OK;
+                        }
+                    }
+                    state = 0;
+                    ++cur;
+                }
+            }
+        }
+    }
+}
+#endif
+
 // berner/sniff.py:21-44
 SDR_HD inline void rule_berner(const EdgeCtx& e, const BackParams& P, DecState* st, int cap,
                                    unsigned char* bits)
 {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (e.wave) {
+        wave_rule_berner(e, P, st, cap);
+        return;
+    }
+#endif
     long long start_tick = 0;
     int state = 0, nbits = 0;
     int level = e.first_level;
@@ -506,10 +571,85 @@ SDR_HD inline void rule_berner(const EdgeCtx& e, const BackParams& P, DecState* 
     }
 }
 
+#if defined(__HIP_DEVICE_COMPILE__)
+// mumbi rule (mumbi/sniff.py:26-65), wavefront form: 64 edges at a time, one per lane -- the time since
+// the previous edge decides both the 8-ms watchdog (any edge) and, on falling edges, the pulse class
+// ("1": 720..920 us, sets the receiving state; "0": 250..350 us).  The masks are walked from watchdog
+// to watchdog: the pulses in between append their bits (only the first 34 are ever looked at), the
+// watchdog emits when exactly 34 were collected in the receiving state.  As in the sequential rule,
+// "0" pulses seen before any "1" stay in the buffer across a watchdog.
+__device__ inline void wave_rule_mumbi(const EdgeCtx& e, const BackParams& P, DecState* st, int cap)
+{
+    const int lane = (int)(threadIdx.x & 63);
+    const int wd = 8000;
+    int state = 0, nbits = 0;
+    unsigned long long acc = 0;   // stream bit i at bit i (i < 34)
+    auto watchdog = [&](long long at) {
+        if (state > 0) {
+            if (nbits == 34) {
+                sdr_frame* f = next_frame(P, st, cap, at);
+                if (f) {
+                    for (int j = 0; j < 5; ++j) f->bytes[j] = __builtin_bitreverse8((unsigned char)((acc >> (8 * j)) & 0xffu));
+                    f->nbits = 34;
+                    f->nbytes = 5;
+                    f->status = SDR_FRAME_OK;
+                }
+            }
+            nbits = 0;
+            acc = 0;
+            state = 0;
+        }
+    };
+    for (long long j0 = 0; 1 + j0 < e.R; j0 += 64) {
+        const long long k = 1 + j0 + lane;
+        const bool in = k < e.R;
+        const int d = in ? sat_delta(tick_of(e, k) - tick_of(e, k - 1)) : 0;
+        const bool falling = in && (int)(k & 1) == e.first_level;
+        const unsigned long long mIn = __ballot(in);
+        unsigned long long mW = __ballot(in && d > wd);
+        const unsigned long long mA = __ballot(falling && in_range(d, 720, 920));
+        const unsigned long long mAB = mA | __ballot(falling && in_range(d, 250, 350));
+        const int nin = __builtin_popcountll(mIn);
+        int cur = 0;
+        while (cur < nin) {
+            const unsigned long long wrest = mW >> cur;
+            const int w = wrest ? cur + __builtin_ctzll(wrest) : nin;
+            // pulses of edges [cur, w)
+            const unsigned long long range = (w >= 64 ? ~0ull : ((1ull << w) - 1ull)) & ~((1ull << cur) - 1ull);
+            unsigned long long ab = mAB & range;
+            if (mA & range) state = 1;
+            while (ab && nbits < 34) {
+                const int p = __builtin_ctzll(ab);
+                acc |= ((mA >> p) & 1ull) << nbits;
+                ++nbits;
+                ab &= ab - 1ull;
+            }
+            nbits += __builtin_popcountll(ab);
+            if (nbits > 512) nbits = 512;
+            if (w < nin) {
+                watchdog(e.pos[1 + j0 + w]);
+                mW &= ~(1ull << w);
+            }
+            cur = w;
+            if (w >= nin) break;
+        }
+    }
+    const long long end_tick = (e.nb * 1000000LL) / e.rate_hz;
+    const long long last_tick = e.R > 1 ? tick_of(e, e.R - 1) : 0;
+    if (sat_delta(end_tick - last_tick) > wd) watchdog(e.nb);
+}
+#endif
+
 // mumbi/sniff.py:26-65 (watchdog 8 ms)
 SDR_HD inline void rule_mumbi(const EdgeCtx& e, const BackParams& P, DecState* st, int cap,
                                   unsigned char* bits)
 {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (e.wave) {
+        wave_rule_mumbi(e, P, st, cap);
+        return;
+    }
+#endif
     const int tol = 50;
     const int wd = 8000;
     long long start_tick = 0, prev_tick = 0;
