@@ -275,6 +275,22 @@ SDR_HD inline void decode_tfa(const double* cur0, int n0, double* scratch, bool 
     f->status = SDR_FRAME_OK;
 }
 
+#if defined(__HIPCC__)
+// Inclusive prefix sum over the 64 lanes in the VALU (DPP row shifts inside the 16-lane rows,
+// then the row totals by row_bcast) instead of six ds_bpermute round trips.
+__device__ __forceinline__ int wave_incl_scan_dpp(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);    // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);    // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);    // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);    // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
+#endif
+
 // ---- pigpio-callback rule decoders on run boundaries ---------------------------
 struct EdgeCtx {
     const int32_t* pos;
@@ -362,10 +378,138 @@ SDR_HD inline sdr_frame* next_frame(const BackParams& P, DecState* st, int cap, 
     return f;
 }
 
+// somfy/sniff.py:84-117 on the collected half-symbols b[0..112): Manchester pairs -> 7 bytes ->
+// de-obfuscation -> checksum -> fields
+SDR_HD inline void somfy_emit(sdr_frame* f, const unsigned char* fr_in, int clock)
+{
+    unsigned char fr[7];
+    for (int i = 0; i < 7; ++i) fr[i] = fr_in[i];
+    for (int i = 0; i < 7; ++i) f->raw[i] = fr[i];
+    for (int i = 6; i > 0; --i) fr[i] = fr[i] ^ fr[i - 1];
+    unsigned int ck = 0;
+    for (int i = 0; i < 7; ++i) ck ^= fr[i] ^ (fr[i] >> 4);
+    ck &= 0xf;
+    f->nbits = 112;
+    f->nbytes = 7;
+    for (int i = 0; i < 7; ++i) f->bytes[i] = fr[i];
+    f->v[0] = (fr[1] >> 4) & 0x0f;
+    f->v[1] = ((int)fr[2] << 8) | fr[3];
+    f->v[2] = (int)fr[4] | ((int)fr[5] << 8) | ((int)fr[6] << 16);
+    f->v[3] = clock;
+    f->status = ck == 0 ? SDR_FRAME_OK : SDR_FRAME_CHECKSUM;
+}
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// somfy rule (somfy/sniff.py:28-117), wavefront form.  The time since the previous edge (every event
+// restarts the rule's clock) is classified for 64 edges at a time, one per lane: watchdog (> 20 ms),
+// wake-up pulse, hardware-sync length, software-sync pulse.  Outside the data state only those few edges
+// are visited (the others cannot change anything there); in the data state the stretch up to the next
+// watchdog is handled in one step: every lane knows how many half-symbols its edge appends (two, one or
+// none, by the clock measured from the sync), a prefix sum places them in the bit buffer.
+__device__ inline void wave_rule_somfy(const EdgeCtx& e, const BackParams& P, DecState* st, int cap, unsigned char* bits)
+{
+    const int lane = (int)(threadIdx.x & 63);
+    const int tol = 100, wd = 20000;
+    int state = 0, nbits = 0, clock = 640, n_sync = 0;
+    double sync_sum = 0.0;
+    auto watchdog = [&](long long at_run) {
+        if (state > 0) {
+            int n = nbits > 0 ? nbits - 1 : 0;
+            const int b0 = nbits > 0 ? 1 : 0;
+            if (n < 112 && n + 1 < 512) bits[b0 + n++] = 0;
+            if (n == 112) {
+                sdr_frame* f = next_frame(P, st, cap, at_run);
+                const unsigned long long m = __ballot(lane < 56 && bits[b0 + 2 * lane] == 0);
+                if (f) {
+                    unsigned char fr[7];
+                    for (int j = 0; j < 7; ++j) fr[j] = __builtin_bitreverse8((unsigned char)((m >> (8 * j)) & 0xffu));
+                    somfy_emit(f, fr, clock);
+                }
+            }
+            nbits = 0;
+            state = 0;
+        }
+    };
+    for (long long j0 = 0; 1 + j0 < e.R; j0 += 64) {
+        const long long k = 1 + j0 + lane;
+        const bool in = k < e.R;
+        const int d = in ? sat_delta(tick_of(e, k) - tick_of(e, k - 1)) : 0;
+        const bool falling = in && (int)(k & 1) == e.first_level;        // end of a pulse
+        const unsigned long long mIn = __ballot(in);
+        unsigned long long mW = __ballot(in && d > wd);
+        const unsigned long long mK = __ballot(falling && in_range(d, 10050 - tol, 10050 + tol));
+        const unsigned long long mH = __ballot(in && in_range(d, 2500 - 2 * tol, 2500 + 2 * tol));
+        const unsigned long long mS = __ballot(falling && in_range(d, 4850 - 2 * tol, 4850 + 2 * tol));
+        const int nin = __builtin_popcountll(mIn);
+        int cur = 0;
+        while (cur < nin) {
+            const unsigned long long below = (1ull << cur) - 1ull;
+            const unsigned long long wrest = mW & ~below;
+            const int w = wrest ? __builtin_ctzll(wrest) : nin;           // next watchdog edge (or end of chunk)
+            if (state == 3) {
+                // data: edges [cur, w) append 2 / 1 / 0 half-symbols of their level
+                const bool mine = in && lane >= cur && lane < w;
+                int c = 0;
+                if (mine) c = in_range(d, 2 * clock - tol, 2 * clock + tol) ? 2 : (in_range(d, clock - tol, clock + tol) ? 1 : 0);
+                const int incl = wave_incl_scan_dpp(c);
+                const int at = nbits + incl - c;
+                const unsigned char v = falling ? 1 : 0;
+                if (c >= 1 && at < 512) bits[at] = v;
+                if (c == 2 && at + 1 < 512) bits[at + 1] = v;
+                const int total = __builtin_amdgcn_readlane(incl, 63);
+                nbits = nbits + total > 512 ? 512 : nbits + total;
+                cur = w;
+            } else {
+                // idle / woken / syncing: only wake-up, sync-length and software-sync edges matter
+                const unsigned long long cand = (mK | mH | mS) & ~below & (w >= 64 ? ~0ull : ((1ull << w) - 1ull));
+                if (!cand)
+                    cur = w;
+                else {
+                    const int p = __builtin_ctzll(cand);
+                    const unsigned long long bit = 1ull << p;
+                    const int dp = __builtin_amdgcn_readlane(d, p);
+                    if (mH & bit) {                                      // either edge, any state <= 2
+                        if (state < 2) {
+                            n_sync = 0;
+                            sync_sum = 0.0;
+                        }
+                        sync_sum += (double)dp;
+                        ++n_sync;
+                        state = 2;
+                    } else if ((mK & bit) && state == 0)
+                        state = 1;
+                    else if ((mS & bit) && state == 2) {
+                        clock = (int)((sync_sum / (double)n_sync) / 4.0);
+                        nbits = 0;
+                        state = 3;
+                    }
+                    cur = p + 1;
+                    continue;
+                }
+            }
+            if (w < nin) {
+                watchdog(e.pos[1 + j0 + w]);
+                mW &= ~(1ull << w);     // the edge itself is then an ordinary edge of the next stretch
+                cur = w;
+            }
+        }
+    }
+    const long long end_tick = (e.nb * 1000000LL) / e.rate_hz;
+    const long long last_tick = e.R > 1 ? tick_of(e, e.R - 1) : 0;
+    if (sat_delta(end_tick - last_tick) > wd) watchdog(e.nb);
+}
+#endif
+
 // somfy/sniff.py:28-117
 SDR_HD inline void rule_somfy(const EdgeCtx& e, const BackParams& P, DecState* st, int cap,
                                   unsigned char* bits /* >= 512 */)
 {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (e.wave) {
+        wave_rule_somfy(e, P, st, cap, bits);
+        return;
+    }
+#endif
     const int tol = 100;
     long long start_tick = 0;
     int state = 0, nbits = 0, clock = 640, n_sync = 0;
@@ -386,19 +530,7 @@ SDR_HD inline void rule_somfy(const EdgeCtx& e, const BackParams& P, DecState* s
                     // np.where(reshape(bits,(-1,2)) == [0,1], 1, 0).ravel()[::2]: first half-symbol == 0
                     for (int i = 0; i < 56; ++i)
                         if (b[2 * i] == 0) fr[i >> 3] |= (unsigned char)(0x80u >> (i & 7));
-                    for (int i = 0; i < 7; ++i) f->raw[i] = fr[i];
-                    for (int i = 6; i > 0; --i) fr[i] = fr[i] ^ fr[i - 1];
-                    unsigned int ck = 0;
-                    for (int i = 0; i < 7; ++i) ck ^= fr[i] ^ (fr[i] >> 4);
-                    ck &= 0xf;
-                    f->nbits = 112;
-                    f->nbytes = 7;
-                    for (int i = 0; i < 7; ++i) f->bytes[i] = fr[i];
-                    f->v[0] = (fr[1] >> 4) & 0x0f;
-                    f->v[1] = ((int)fr[2] << 8) | fr[3];
-                    f->v[2] = (int)fr[4] | ((int)fr[5] << 8) | ((int)fr[6] << 16);
-                    f->v[3] = clock;
-                    f->status = ck == 0 ? SDR_FRAME_OK : SDR_FRAME_CHECKSUM;
+                    somfy_emit(f, fr, clock);
                 }
             }
             nbits = 0;

@@ -10,19 +10,6 @@
 #pragma once
 #include "backend_kernels.h"
 
-// Inclusive prefix sum over the 64 lanes in the VALU (DPP row shifts inside the 16-lane rows,
-// then the row totals by row_bcast) instead of six ds_bpermute round trips.
-__device__ __forceinline__ int wave_incl_scan_dpp(int v)
-{
-    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);    // row_shr:1
-    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);    // row_shr:2
-    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);    // row_shr:4
-    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);    // row_shr:8
-    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
-    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
-    return v;
-}
-
 __device__ __forceinline__ void wave_sync()
 {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
