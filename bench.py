@@ -441,7 +441,8 @@ def mixed_emitters_workload(torch, dev, skip_cpu, ncap=1250, n=N_PER_CAPTURE, fs
 def pfb_workload(torch, dev, skip_cpu, n=1 << 26, fs=20e6, steps=10):
     """Secondary line (BASELINE.json configs[4]): one 2^26-sample wideband capture at 20 Msps
     -> 64 sub-bands of 312.5 kHz (481-tap prototype, 8 per branch) -> mag^2 -> threshold ->
-    slicer -> keep_one_in_n(16) -> TS33C decoder on every channel."""
+    slicer -> keep_one_in_n(16) -> the TS33C stream decoder and the somfy / berner / mumbi rule decoders
+    over every channel (sdr_redecode); a TS33C, a berner and a mumbi transmitter sit in three sub-bands."""
     from sdr_amd import chain, synth, _lib
     M, keep = 64, 16
     rate = fs / M / keep
@@ -450,35 +451,65 @@ def pfb_workload(torch, dev, skip_cpu, n=1 << 26, fs=20e6, steps=10):
     sym = []
     for _ in range(3):
         sym += synth.ts33c_symbols(synth.ts33c_bits(pkt), rng)
-    ch = 5
-    env = torch.from_numpy(synth.envelope(sym, fs, lead_in_us=5000.0, total=n)).to(dev)
+    ch, ch_berner, ch_mumbi = 5, 40, 17
+    berner_code = int(rng.integers(0, 1 << 32))
+    codes = sorted(synth.MUMBI_CODES)
+    mumbi_code = bytes(bytearray(synth.MUMBI_CODES[codes[int(rng.integers(0, len(codes)))]]))
+    mumbi_want = bytes(bytearray([mumbi_code[0], mumbi_code[1], mumbi_code[2], mumbi_code[3], mumbi_code[4] & 0xC0]))
+    emitters = [(ch, sym, 5000.0), (ch_berner, synth.berner_symbols(berner_code, repeats=5), 150000.0),
+                (ch_mumbi, synth.mumbi_symbols(mumbi_code, repeats=8), 400000.0)]
     g = torch.Generator(device=dev)
     g.manual_seed(64)
     iq = 0.02 * torch.randn((n, 2), generator=g, device=dev, dtype=torch.float32)
     step_n = 1 << 22
-    for a in range(0, n, step_n):
-        t = torch.arange(a, a + step_n, dtype=torch.float64, device=dev)
-        ph = (2 * np.pi * ch / M) * t
-        e = env[a:a + step_n].to(torch.float32) * 0.5
-        iq[a:a + step_n, 0] += e * torch.cos(ph).to(torch.float32)
-        iq[a:a + step_n, 1] += e * torch.sin(ph).to(torch.float32)
-    del env
+    for chan, esym, lead in emitters:
+        env = torch.from_numpy(synth.envelope(esym, fs, lead_in_us=lead, total=n)).to(dev)
+        for a in range(0, n, step_n):
+            t = torch.arange(a, a + step_n, dtype=torch.float64, device=dev)
+            ph = (2 * np.pi * chan / M) * t
+            e = env[a:a + step_n].to(torch.float32) * 0.5
+            iq[a:a + step_n, 0] += e * torch.cos(ph).to(torch.float32)
+            iq[a:a + step_n, 1] += e * torch.sin(ph).to(torch.float32)
+        del env
     taps = chain.low_pass(1.0, fs, 100e3, 100e3)
     c = chain.Chain(fs, taps=taps, keep_n=keep, decoder=chain.DEC_TS33C, decoder_rate=rate, max_samples=n,
                     max_frames=64, channels=M)
     c.set_stream(torch.cuda.current_stream().cuda_stream)
     x = iq.reshape(1, n, 2)
+    rules = (chain.DEC_SOMFY, chain.DEC_BERNER, chain.DEC_MUMBI)
+
+    def step(collect=None):
+        c.batch_process(x)                      # channelizer + TS33C stream decoder on the 64 rows
+        if collect is not None:
+            collect[chain.DEC_TS33C] = c.fetch_frames()
+        for d in rules:                         # further decoders over the same sliced rows
+            c.redecode(d, rate)
+            if collect is not None:
+                collect[d] = c.fetch_frames()
+
     for _ in range(3):
-        c.batch_process(x)
+        step()
     torch.cuda.synchronize()
     c.profile_enable(True)
     t0 = time.perf_counter()
     for _ in range(steps):
-        c.batch_process(x)
+        step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     front_ms, back_ms = c.profile_read()
-    good = [f for f in c.fetch_frames() if f.status == _lib.FRAME_OK]
+    c.profile_enable(False)
+    per = 1 + len(rules)                        # profile slots per step: channelizer pass + one per further decoder
+    front_ms, back_ms = front_ms[0::per], [sum(back_ms[i:i + per]) for i in range(0, len(back_ms) - per + 1, per)]
+    got = {}
+    step(got)
+    good = [f for f in got[chain.DEC_TS33C] if f.status == _lib.FRAME_OK]
+    fb, fm = got[chain.DEC_BERNER], got[chain.DEC_MUMBI]
+    if not fb or any(f.capture != ch_berner for f in fb) or fb[0].packet() != berner_code.to_bytes(4, "big"):
+        raise SystemExit("channelizer: berner frames %s" % [(f.capture, f.packet().hex()) for f in fb])
+    if not fm or any(f.capture != ch_mumbi for f in fm) or not any(f.packet() == mumbi_want for f in fm):
+        raise SystemExit("channelizer: mumbi frames %s" % [(f.capture, f.packet().hex()) for f in fm])
+    if got[chain.DEC_SOMFY]:
+        raise SystemExit("channelizer: somfy frames without a somfy transmitter")
     if [f.capture for f in good] != [ch] * len(good) or [f.packet() for f in good] != [pkt] * 3:
         raise SystemExit("channelizer: expected the 3 transmitted frames in channel %d, got %s"
                          % (ch, [(f.capture, f.packet().hex()) for f in good]))
@@ -487,13 +518,15 @@ def pfb_workload(torch, dev, skip_cpu, n=1 << 26, fs=20e6, steps=10):
     ach = bps * n / (fk * 1e-3) / 1e9
     out = {"value": round(n / dt / 1e6, 1), "unit": "Msps", "ms_per_step": round(dt * 1e3, 4), "samples": n,
            "sample_rate": fs, "channels": M, "ntaps": int(taps.size), "keep_n": keep,
-           "chain": "pfb64->mag2->threshold->slicer->keep_one_in_n->ts33c_decoder per channel",
+           "chain": "pfb64->mag2->threshold->slicer->keep_one_in_n->{ts33c, somfy, berner, mumbi} decoders per channel",
+           "decoder_passes_per_step": 4,
            "roofline": {"bound": "hbm", "kernel": "k_pfb<8>", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                         "traffic": pmc_traffic("k_pfb<8>", "samples=2^%d" % int(np.log2(n)))[0],
                         "kernel_ms": round(fk, 4), "backend_kernel_ms": round(float(np.mean(back_ms)), 4),
                         "bytes_per_launch": bps * n},
-           "verified": "the 3 transmitted frames decode in channel 5, no other channel yields a valid frame"}
+           "verified": "the 3 TS33C frames decode in channel 5, the berner code in channel 40, the mumbi code in "
+                       "channel 17, nothing valid anywhere else"}
     if not skip_cpu:
         from oracle import dsp as odsp
         m = 1 << 21

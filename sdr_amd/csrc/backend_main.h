@@ -250,7 +250,20 @@ __global__ void __launch_bounds__(BK_THREADS, 6) k_backend(BackParams P)
     bool runs_overflow = false;
     bool w_in_lds = false, pos_in_lds = false;
     int first_level = 0, last_level = 0;
-    if (fast) {
+    if (P.reuse_runs) {
+        // a further decoder over rows whose run table the previous launch has left in place
+        // (sdr_redecode): only the LDS mirror of the run starts is refilled
+        const unsigned rn = (unsigned)P.runs_n[cap];
+        R = nb > 0 ? (long long)(rn & 0x7fffffffu) : 0;
+        runs_overflow = (rn >> 31) != 0;
+        w_in_lds = R <= SDR_CUR_CAP;
+        pos_in_lds = R + 1 <= 2048;
+        if (pos_in_lds)
+            for (long long k = tid; k <= R; k += BK_THREADS) s_pos[k] = pos[k];
+        first_level = nb > 0 ? (bits[0] != 0) : 0;
+        last_level = nb > 0 ? (bits[nb - 1] != 0) : 0;
+        __syncthreads();
+    } else if (fast) {
         if (tid == 0) {
             pos[0] = 0;
             s_pos[0] = 0;
@@ -351,6 +364,7 @@ __global__ void __launch_bounds__(BK_THREADS, 6) k_backend(BackParams P)
     __syncthreads();  // pos[] (global) written by this block is read back below
     (void)b_in_lds;
     }
+    if (tid == 0 && P.runs_n && !P.reuse_runs) P.runs_n[cap] = (int32_t)((unsigned)R | (runs_overflow ? 0x80000000u : 0u));
     if (nb == 0) return;
 
     // run widths (stream decoders) or edge ticks (callback rules) into LDS

@@ -161,7 +161,9 @@ extern "C" int sdr_redecode(sdr_handle* h, int decoder, double decoder_rate)
         run = ((double)g.ne * 1e6 / h->dec_rate > decoder_reset_limit(decoder)) ? 1 : 0;
     if (h->profile) HIPCHK(h, hipEventRecord(h->pev[3 * (h->pcount % SDR_PROF_RING)], h->stream));
     // bits are final (tsum == nullptr): phase 0 is skipped, thr_state untouched
+    h->reuse_next = true;   // the run table of the batch's own pass (or of an earlier redecode) is still valid
     int r = launch_back(h, h->last_ncap, g, 0, g.ne, 1, 0, run);
+    h->reuse_next = false;
     h->cfg.decoder = keep_dec;
     h->dec_rate = keep_rate;
     return r;

@@ -162,4 +162,6 @@ struct BackParams {
     long long seg_bytes;    // multiple of the 16-KiB round
     int32_t* runs_seg;      // per capture bits_stride ints: segment s keeps its edges from index s*seg_bytes on
     int32_t* seg_cnt;       // per capture nseg counts
+    int32_t* runs_n;        // per capture: number of runs the last full pass found (bit 31: table overflowed)
+    int reuse_runs;         // 1: phase 1 is skipped, runs and runs_n come from that pass
 };

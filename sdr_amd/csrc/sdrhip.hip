@@ -62,6 +62,9 @@ struct sdr_handle {
     int32_t* d_runs = nullptr;
     int32_t* d_runs_seg = nullptr;  // rows of SDR_SEG_MIN_ROW bytes and more: per-segment run starts (k_runs_seg)
     int32_t* d_seg_cnt = nullptr;
+    int32_t* d_runs_n = nullptr;    // runs per capture left by the last full back-end pass
+    bool runs_valid = false;        // ... and whether they describe the current sliced bytes
+    bool reuse_next = false;        // set by sdr_redecode around its launch_back
     long long runs_cap = 0;
     double* d_cur = nullptr;
     DecState* d_st = nullptr;
@@ -441,7 +444,7 @@ extern "C" int sdr_destroy(sdr_handle* h)
     }
     if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
     void* ptrs[] = {h->d_rtaps, h->d_post_rtaps, h->d_nco_tab, h->d_atan_tab, h->d_pow, h->d_log2, h->d_iq,
-                    h->d_hist[0], h->d_hist[1], h->d_bits, h->d_tap, h->d_tap2, h->d_tsum, h->d_runs, h->d_runs_seg, h->d_seg_cnt,
+                    h->d_hist[0], h->d_hist[1], h->d_bits, h->d_tap, h->d_tap2, h->d_tsum, h->d_runs, h->d_runs_seg, h->d_seg_cnt, h->d_runs_n,
                     h->d_cur, h->d_st, h->d_frames, h->d_sq_y, h->d_sq_z, h->d_sq_cnt, h->d_sq_st,
                     h->d_post_hist[0], h->d_post_hist[1], h->d_pack, h->d_pfb_taps, h->d_pfb_tw};
     for (void* p : ptrs)
@@ -527,6 +530,7 @@ extern "C" int sdr_create(const sdr_chain_cfg* cfg, sdr_handle** out)
         HIPCHK(h, dev_alloc((void**)&h->d_tsum, (size_t)(B * h->tsum_stride) * sizeof(TileSum)));
         h->runs_cap = h->bits_stride;
         HIPCHK(h, dev_alloc((void**)&h->d_runs, (size_t)(B * (h->runs_cap + 2)) * sizeof(int32_t)));
+        HIPCHK(h, dev_alloc((void**)&h->d_runs_n, (size_t)B * sizeof(int32_t)));
         if (h->bits_stride >= SDR_SEG_MIN_ROW) {
             HIPCHK(h, dev_alloc((void**)&h->d_runs_seg, (size_t)(B * h->bits_stride) * sizeof(int32_t)));
             HIPCHK(h, dev_alloc((void**)&h->d_seg_cnt, (size_t)(B * BK_THREADS) * sizeof(int32_t)));
@@ -958,7 +962,12 @@ static int launch_back(sdr_handle* h, int ncap, const CallGeom& g, long long pat
     Bp.max_frames = c.max_frames;
     Bp.pow_m13 = h->d_pow;
     Bp.log2n = h->d_log2;
-    if (h->d_runs_seg && !Bp.nout_var && run_decoder && c.decoder != SDR_DEC_NONE && nb_total >= SDR_SEG_MIN_ROW &&
+    Bp.runs_n = h->d_runs_n;
+    const bool full_pass = run_decoder && c.decoder != SDR_DEC_NONE && !Bp.nout_var;
+    if (h->reuse_next && h->runs_valid && full_pass && !getenv("SDR_NO_REUSE")) {
+        Bp.reuse_runs = 1;
+        hipLaunchKernelGGL(k_backend, dim3(ncap), dim3(BK_THREADS), 0, h->stream, Bp);
+    } else if (h->d_runs_seg && !Bp.nout_var && run_decoder && c.decoder != SDR_DEC_NONE && nb_total >= SDR_SEG_MIN_ROW &&
         !getenv("SDR_NO_SEG")) {
         // long rows: carries first (they patch the bytes), then the run starts of every 64-KiB-or-more
         // segment by its own workgroup, then the decoders on the gathered run table
@@ -979,6 +988,7 @@ static int launch_back(sdr_handle* h, int ncap, const CallGeom& g, long long pat
     } else
         hipLaunchKernelGGL(k_backend, dim3(ncap), dim3(BK_THREADS), 0, h->stream, Bp);
     HIPCHK(h, hipGetLastError());
+    if (!Bp.reuse_runs) h->runs_valid = full_pass;
     if (h->profile) {
         HIPCHK(h, hipEventRecord(h->pev[3 * (h->pcount % SDR_PROF_RING) + 2], h->stream));
         h->pcount++;
