@@ -831,11 +831,146 @@ SDR_HD inline void rule_mumbi(const EdgeCtx& e, const BackParams& P, DecState* s
     if (sat_delta(end_tick - prev_tick) > wd) watchdog(e.nb);
 }
 
+// kwmobile/decoder.py:112-131 fields of the 36-bit frame (5 packed bytes)
+SDR_HD inline void kwmobile_fill(sdr_frame* f, const unsigned char* b)
+{
+    for (int j = 0; j < 5; ++j) f->bytes[j] = b[j];
+    f->nbits = 36;
+    f->nbytes = 5;
+    f->temp_tenths = ((b[1] & 0x0f) << 8) | b[2];
+    f->v[0] = b[0];                                   // sensor_id
+    f->v[1] = ((b[3] & 0x0f) << 4) + (b[4] >> 4);     // humidity
+    f->v[2] = (b[1] & 0x80) == 0x80;                  // battery_ok
+    f->v[3] = (b[1] & 0x30) >> 4;                     // channel
+    f->status = SDR_FRAME_OK;
+}
+
+// baldr/decoder.py:118-139 fields of the 37-bit frame
+SDR_HD inline void baldr_fill(sdr_frame* f, const unsigned char* b)
+{
+    for (int j = 0; j < 5; ++j) f->bytes[j] = b[j];
+    f->nbits = 37;
+    f->nbytes = 5;
+    int t = ((int)b[2] << 4) | (b[3] >> 4);
+    if (t > 0x7ff) t -= 4096;
+    f->temp_tenths = t;
+    f->v[0] = ((b[0] & 0x0f) << 4) | (b[1] >> 4);     // sensor_id
+    f->v[1] = ((b[3] & 0x07) << 4) | (b[4] >> 4);     // humidity
+    f->v[2] = b[1] & 0x04;                            // txMode
+    f->v[3] = b[1] & 0x03;                            // channel
+    f->status = SDR_FRAME_OK;
+}
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// PPM rules (kwmobile / baldr), wavefront form.  Only rising edges carry information: the time since
+// the previous rising edge is a preamble, a "1" or a "0"; the time since the previous edge of either
+// kind drives the watchdog.  64 edges per step, one per lane; the masks are walked from watchdog to
+// watchdog.  BALDR: a second preamble-length gap ends the frame (kept for the watchdog if exactly
+// 37 bits were collected, dropped otherwise), as baldr/decoder.py:104-110.
+template <bool BALDR>
+__device__ inline void wave_rule_ppm(const EdgeCtx& e, const BackParams& P, DecState* st, int cap)
+{
+    const int lane = (int)(threadIdx.x & 63);
+    const int wd = BALDR ? 18000 : 3000, want = BALDR ? 37 : 36;
+    const int pre_lo = BALDR ? 9600 - 200 : 4500 - 200, pre_hi = BALDR ? 9600 + 200 : 4500 + 200;
+    const int one_lo = BALDR ? 4700 - 200 : 2500 - 100, one_hi = BALDR ? 4700 + 200 : 2500 + 100;
+    const int zer_lo = BALDR ? 2650 - 200 : 1500 - 100, zer_hi = BALDR ? 2650 + 200 : 1500 + 100;
+    int state = 0, nbits = 0;
+    unsigned long long acc = 0;   // stream bit i at bit i (first 64)
+    auto watchdog = [&](long long at) {
+        if (state > 0) {
+            if (nbits == want) {
+                sdr_frame* f = next_frame(P, st, cap, at);
+                if (f) {
+                    unsigned char b[5];
+                    for (int j = 0; j < 5; ++j) b[j] = __builtin_bitreverse8((unsigned char)((acc >> (8 * j)) & 0xffu));
+                    if (BALDR)
+                        baldr_fill(f, b);
+                    else
+                        kwmobile_fill(f, b);
+                }
+            }
+            nbits = 0;
+            acc = 0;
+            state = 0;
+        }
+    };
+    auto append = [&](unsigned long long ones, unsigned long long any) {   // pulses of one stretch, in edge order
+        while (any && nbits < 64) {
+            const int p = __builtin_ctzll(any);
+            acc |= ((ones >> p) & 1ull) << nbits;
+            ++nbits;
+            any &= any - 1ull;
+        }
+        nbits += __builtin_popcountll(any);
+        if (nbits > 512) nbits = 512;
+    };
+    for (long long j0 = 0; 1 + j0 < e.R; j0 += 64) {
+        const long long k = 1 + j0 + lane;
+        const bool in = k < e.R;
+        const long long tk = in ? tick_of(e, k) : 0;
+        const int d1 = in ? sat_delta(tk - tick_of(e, k - 1)) : 0;
+        const bool rising = in && (int)(k & 1) != e.first_level;
+        const int dr = rising ? sat_delta(tk - (k >= 2 ? tick_of(e, k - 2) : 0)) : 0;
+        const unsigned long long mIn = __ballot(in);
+        unsigned long long mW = __ballot(in && d1 > wd);
+        const unsigned long long mP = __ballot(rising && in_range(dr, pre_lo, pre_hi));
+        const unsigned long long m1 = __ballot(rising && in_range(dr, one_lo, one_hi));
+        const unsigned long long m01 = m1 | __ballot(rising && in_range(dr, zer_lo, zer_hi));
+        const int nin = __builtin_popcountll(mIn);
+        int cur = 0;
+        while (cur < nin) {
+            const unsigned long long below = (1ull << cur) - 1ull;
+            const unsigned long long wrest = mW & ~below;
+            const int w = wrest ? __builtin_ctzll(wrest) : nin;
+            const unsigned long long upto = w >= 64 ? ~0ull : ((1ull << w) - 1ull);
+            const unsigned long long pre = mP & ~below & upto;
+            if (state == 0) {
+                if (pre) {
+                    state = 1;
+                    cur = __builtin_ctzll(pre) + 1;
+                    continue;
+                }
+            } else if (state == 1) {
+                if (BALDR && pre) {
+                    const int p = __builtin_ctzll(pre);
+                    append(m1, m01 & ~below & ((1ull << p) - 1ull));
+                    if (nbits == want)
+                        state = 2;
+                    else {
+                        nbits = 0;
+                        acc = 0;
+                        state = 0;
+                    }
+                    cur = p + 1;
+                    continue;
+                }
+                append(m1, m01 & ~below & upto);
+            }
+            if (w < nin) {
+                watchdog(e.pos[1 + j0 + w]);
+                mW &= ~(1ull << w);
+            }
+            cur = w;
+        }
+    }
+    const long long end_tick = (e.nb * 1000000LL) / e.rate_hz;
+    const long long last_tick = e.R > 1 ? tick_of(e, e.R - 1) : 0;
+    if (sat_delta(end_tick - last_tick) > wd) watchdog(e.nb);
+}
+#endif
+
 // kwmobile/decoder.py:95-135 (Nexus-type PPM sensor; watchdog 3 ms, :145).  Only the
 // rising edges matter: delta = time between consecutive ends of gap.
 SDR_HD inline void rule_kwmobile(const EdgeCtx& e, const BackParams& P, DecState* st, int cap,
                                  unsigned char* bits)
 {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (e.wave) {
+        wave_rule_ppm<false>(e, P, st, cap);
+        return;
+    }
+#endif
     const int tol = 50;
     const int wd = 3000;
     long long start_tick = 0, prev_tick = 0;
@@ -848,15 +983,7 @@ SDR_HD inline void rule_kwmobile(const EdgeCtx& e, const BackParams& P, DecState
                 if (f) {
                     unsigned char b[5];
                     pack_bits_msb(e, bits, 36, b);
-                    for (int j = 0; j < 5; ++j) f->bytes[j] = b[j];
-                    f->nbits = 36;
-                    f->nbytes = 5;
-                    f->temp_tenths = ((b[1] & 0x0f) << 8) | b[2];
-                    f->v[0] = b[0];                                   // sensor_id
-                    f->v[1] = ((b[3] & 0x0f) << 4) + (b[4] >> 4);     // humidity
-                    f->v[2] = (b[1] & 0x80) == 0x80;                  // battery_ok
-                    f->v[3] = (b[1] & 0x30) >> 4;                     // channel
-                    f->status = SDR_FRAME_OK;
+                    kwmobile_fill(f, b);
                 }
             }
             nbits = 0;
@@ -894,6 +1021,12 @@ SDR_HD inline void rule_kwmobile(const EdgeCtx& e, const BackParams& P, DecState
 SDR_HD inline void rule_baldr(const EdgeCtx& e, const BackParams& P, DecState* st, int cap,
                               unsigned char* bits)
 {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (e.wave) {
+        wave_rule_ppm<true>(e, P, st, cap);
+        return;
+    }
+#endif
     const int tol = 200;
     const int wd = 18000;
     const int medium = 2650, lng = 4700, verylong = 9600;
@@ -907,17 +1040,7 @@ SDR_HD inline void rule_baldr(const EdgeCtx& e, const BackParams& P, DecState* s
                 if (f) {
                     unsigned char b[5];
                     pack_bits_msb(e, bits, 37, b);
-                    for (int j = 0; j < 5; ++j) f->bytes[j] = b[j];
-                    f->nbits = 37;
-                    f->nbytes = 5;
-                    int t = ((int)b[2] << 4) | (b[3] >> 4);
-                    if (t > 0x7ff) t -= 4096;
-                    f->temp_tenths = t;
-                    f->v[0] = ((b[0] & 0x0f) << 4) | (b[1] >> 4);     // sensor_id
-                    f->v[1] = ((b[3] & 0x07) << 4) | (b[4] >> 4);     // humidity
-                    f->v[2] = b[1] & 0x04;                            // txMode
-                    f->v[3] = b[1] & 0x03;                            // channel
-                    f->status = SDR_FRAME_OK;
+                    baldr_fill(f, b);
                 }
             }
             nbits = 0;
