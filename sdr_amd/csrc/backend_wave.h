@@ -328,8 +328,57 @@ __device__ inline void wave_stream_decode(const BackParams& P, int cap, WF W, co
     const bool size_is_1 = (npieces == 1 && R == 1);
     if (npieces > 1) st->state = 1;
     double* cur = L.cur;
+    // Long rows (P.pieces_hdr): every piece that both starts behind and ends with an over-limit width is
+    // a packet of its own -- the piece before it has left no pending symbols -- so only the first and the
+    // last piece are walked here and the pieces in between go to k_decode_pieces, one wavefront each.
+    // Their bounds (run index behind each over-limit width) are left in pieces_b; a middle piece longer
+    // than the pending-symbol table keeps the row on the sequential path (its overflow semantics).
+    bool delegate = false;
+    long long last_b = 0, nf_mid = 0;
+    if (P.pieces_hdr && npieces >= 4) {
+        int32_t* pb = P.pieces_b + (long long)cap * P.bits_stride;
+        long long base = 0;
+        bool too_long = false;
+        for (long long k0 = 0; k0 < R; k0 += 64) {
+            const long long k = k0 + lane;
+            const bool over = k < R && W(k) > reset_limit;
+            const unsigned long long m = __ballot(over);
+            if (!m) continue;
+            const unsigned long long below = m & lanemask_lt();
+            const long long prev = below ? k0 + (63 - __builtin_clzll(below)) + 1 : last_b;
+            const long long idx = base + __builtin_popcountll(below);      // piece number this width closes
+            const long long len = k + 1 - prev;
+            if (over) pb[idx] = (int32_t)(k + 1);
+            too_long = too_long || __ballot(over && idx >= 1 && len > SDR_CUR_CAP) != 0;
+            nf_mid += __builtin_popcountll(__ballot(over && idx >= 1 && len >= 2));
+            base += __builtin_popcountll(m);
+            last_b = k0 + (63 - __builtin_clzll(m)) + 1;
+        }
+        delegate = !too_long;
+    }
     long long a = 0;
     for (long long pc = 0; pc < npieces; ++pc) {
+        if (delegate && pc == 1) {
+            if (st->n_cur != 0 || (st->overflow & 4))
+                delegate = false;            // the first piece did not end clean: walk the row as before
+            else {
+                int32_t* hdr = P.pieces_hdr + (long long)cap * 8;
+                const long long f1 = st->n_frames;
+                if (lane == 0) {
+                    hdr[1] = (int32_t)n_over;
+                    hdr[2] = (int32_t)f1;
+                    hdr[3] = (int32_t)nf_mid;
+                    hdr[0] = 1;
+                }
+                if (f1 + nf_mid > P.max_frames) {
+                    st->overflow |= 2;
+                    st->n_frames = P.max_frames;
+                } else
+                    st->n_frames = (int)(f1 + nf_mid);
+                a = last_b;
+                pc = npieces - 1;
+            }
+        }
         long long b;
         if (pc == npieces - 1)
             b = R;
@@ -392,4 +441,55 @@ __device__ inline void wave_stream_decode(const BackParams& P, int cap, WF W, co
         a = b;
     }
     st->prev_type = last_level;
+}
+
+// The closed middle pieces of a long row (see wave_stream_decode): piece i = runs [b[i-1], b[i]),
+// one wavefront per piece, frame slot = frames of the first piece + number of earlier middle pieces
+// that hold a packet (two symbols or more).  TS33C: the decoder keeps the limits of the LAST decoded
+// packet as attributes; the piece that owns the last frame slot writes them.
+__global__ void __launch_bounds__(64) k_decode_pieces(BackParams P)
+{
+    __shared__ __align__(16) double s_cur[SDR_CUR_CAP];
+    __shared__ __align__(16) double s_scr[SDR_CUR_CAP];
+    __shared__ unsigned int s_words[64];
+    __shared__ unsigned char s_par[256];
+    const int cap = blockIdx.y, lane = threadIdx.x & 63;
+    const int32_t* hdr = P.pieces_hdr + (long long)cap * 8;
+    if (hdr[0] != 1) return;
+    const long long n_over = hdr[1], f1 = hdr[2], nf_mid = hdr[3];
+    const int32_t* pb = P.pieces_b + (long long)cap * P.bits_stride;
+    const int32_t* pos = P.runs + (long long)cap * (P.runs_cap + 2);
+    const WidthsFromPos W{pos, P.dec_rate};
+    const bool ts33c = P.decoder == SDR_DEC_TS33C;
+    const long long total = f1 + nf_mid > P.max_frames ? P.max_frames : f1 + nf_mid;
+    DecState* st = P.st + cap;
+    const WaveLds L{s_cur, s_scr, s_words, s_par};
+    for (long long i = 1 + blockIdx.x; i <= n_over - 1; i += gridDim.x) {
+        const long long a = pb[i - 1], b = pb[i];
+        const long long len = b - a;
+        if (len < 2) continue;
+        long long cnt = 0;
+        for (long long j0 = 1; j0 < i; j0 += 64) {
+            const long long j = j0 + lane;
+            cnt += __builtin_popcountll(__ballot(j < i && pb[j] - pb[j - 1] >= 2));
+        }
+        const long long slot = f1 + cnt;
+        if (slot >= P.max_frames) continue;
+        for (long long t = lane; t < len; t += 64) s_cur[t] = W(a + t);
+        sdr_frame* f = P.frames + (long long)cap * P.max_frames + slot;
+        if (lane == 0) frame_init(f, cap, P.decoder, pos[b]);
+        wave_sync();
+        if (ts33c) {
+            DecState tmp;
+            tmp.pulse_short_limit = 0.0;
+            tmp.gap_short_limit = 0.0;
+            wave_decode_ts33c(L, (int)len, 1550.0, &tmp, P, f);
+            if (slot == total - 1 && lane == 0) {
+                st->pulse_short_limit = tmp.pulse_short_limit;
+                st->gap_short_limit = tmp.gap_short_limit;
+            }
+        } else
+            wave_decode_tfa(L, (int)len, P.decoder == SDR_DEC_TFA_GRC, f);
+        wave_sync();
+    }
 }

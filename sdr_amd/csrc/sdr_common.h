@@ -164,4 +164,8 @@ struct BackParams {
     int32_t* seg_cnt;       // per capture nseg counts
     int32_t* runs_n;        // per capture: number of runs the last full pass found (bit 31: table overflowed)
     int reuse_runs;         // 1: phase 1 is skipped, runs and runs_n come from that pass
+    // long rows, stream decoders: the closed pieces between the first and the last are decoded by
+    // k_decode_pieces, one wavefront each
+    int32_t* pieces_b;      // per capture (bits_stride ints, the runs_seg slice): run index behind every over-limit width
+    int32_t* pieces_hdr;    // per capture 8 ints: [0] 1 = delegated, [1] over-limit widths, [2] frames of the first piece, [3] frames of the middle pieces
 };

@@ -63,6 +63,7 @@ struct sdr_handle {
     int32_t* d_runs_seg = nullptr;  // rows of SDR_SEG_MIN_ROW bytes and more: per-segment run starts (k_runs_seg)
     int32_t* d_seg_cnt = nullptr;
     int32_t* d_runs_n = nullptr;    // runs per capture left by the last full back-end pass
+    int32_t* d_pieces_hdr = nullptr; // long rows: 8 ints per capture for k_decode_pieces
     bool runs_valid = false;        // ... and whether they describe the current sliced bytes
     bool reuse_next = false;        // set by sdr_redecode around its launch_back
     long long runs_cap = 0;
@@ -444,7 +445,7 @@ extern "C" int sdr_destroy(sdr_handle* h)
     }
     if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
     void* ptrs[] = {h->d_rtaps, h->d_post_rtaps, h->d_nco_tab, h->d_atan_tab, h->d_pow, h->d_log2, h->d_iq,
-                    h->d_hist[0], h->d_hist[1], h->d_bits, h->d_tap, h->d_tap2, h->d_tsum, h->d_runs, h->d_runs_seg, h->d_seg_cnt, h->d_runs_n,
+                    h->d_hist[0], h->d_hist[1], h->d_bits, h->d_tap, h->d_tap2, h->d_tsum, h->d_runs, h->d_runs_seg, h->d_seg_cnt, h->d_runs_n, h->d_pieces_hdr,
                     h->d_cur, h->d_st, h->d_frames, h->d_sq_y, h->d_sq_z, h->d_sq_cnt, h->d_sq_st,
                     h->d_post_hist[0], h->d_post_hist[1], h->d_pack, h->d_pfb_taps, h->d_pfb_tw};
     for (void* p : ptrs)
@@ -534,6 +535,7 @@ extern "C" int sdr_create(const sdr_chain_cfg* cfg, sdr_handle** out)
         if (h->bits_stride >= SDR_SEG_MIN_ROW) {
             HIPCHK(h, dev_alloc((void**)&h->d_runs_seg, (size_t)(B * h->bits_stride) * sizeof(int32_t)));
             HIPCHK(h, dev_alloc((void**)&h->d_seg_cnt, (size_t)(B * BK_THREADS) * sizeof(int32_t)));
+            HIPCHK(h, dev_alloc((void**)&h->d_pieces_hdr, (size_t)(B * 8) * sizeof(int32_t)));
         }
         HIPCHK(h, dev_alloc((void**)&h->d_cur, (size_t)(B * SDR_CUR_CAP) * sizeof(double)));
         HIPCHK(h, dev_alloc((void**)&h->d_st, (size_t)B * sizeof(DecState)));
@@ -543,6 +545,8 @@ extern "C" int sdr_create(const sdr_chain_cfg* cfg, sdr_handle** out)
             if (r2) return r2;
         }
         HIPCHK(h, dev_alloc((void**)&h->d_frames, (size_t)(B * h->cfg.max_frames) * sizeof(sdr_frame)));
+        // the record has 4 bytes of alignment padding no field assignment reaches: keep them defined
+        HIPCHK(h, hipMemset(h->d_frames, 0, (size_t)(B * h->cfg.max_frames) * sizeof(sdr_frame)));
         h->keep_ctr = h->cfg.keep_n;
         return SDR_OK;
     };
@@ -984,7 +988,14 @@ static int launch_back(sdr_handle* h, int ncap, const CallGeom& g, long long pat
         Bp.phase_sel = 2;
         Bp.tsum = nullptr;
         Bp.fresh = 0;
+        const bool pieces = is_stream_decoder(c.decoder) && !getenv("SDR_NO_PIECES");
+        if (pieces) {
+            Bp.pieces_b = h->d_runs_seg;
+            Bp.pieces_hdr = h->d_pieces_hdr;
+            HIPCHK(h, hipMemsetAsync(h->d_pieces_hdr, 0, (size_t)ncap * 8 * sizeof(int32_t), h->stream));
+        }
         hipLaunchKernelGGL(k_backend, dim3(ncap), dim3(BK_THREADS), 0, h->stream, Bp);
+        if (pieces) hipLaunchKernelGGL(k_decode_pieces, dim3(256, ncap), dim3(64), 0, h->stream, Bp);
     } else
         hipLaunchKernelGGL(k_backend, dim3(ncap), dim3(BK_THREADS), 0, h->stream, Bp);
     HIPCHK(h, hipGetLastError());

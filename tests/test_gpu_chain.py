@@ -533,3 +533,45 @@ def test_long_row_segment_parallel_run_length(extra, monkeypatch):
     for of, gf in zip(o2.frames, frames):
         assert_tfa_equal(of, gf)
     assert [f.packet() for f in frames if f.status == 0] == pkts
+
+
+def test_long_row_pieces_decoded_in_parallel_ts33c(monkeypatch):
+    """Rows of 128 KiB and more with four or more pieces: the closed middle pieces are decoded by
+    k_decode_pieces, one wavefront each.  Frame records (status, limits from the histogram, packet,
+    fields, end position) identical to the sequential walk (SDR_NO_PIECES=1) and equal to the oracle;
+    junk bursts give error frames in the same slots; a frame table that is too small overflows alike."""
+    rate = 1000000
+    rng = np.random.default_rng(99)
+    sym = []
+    for i in range(7):
+        pkt = synth.ts33c_packet(**synth.random_ts33c_fields(rng))
+        sym += synth.ts33c_symbols(synth.ts33c_bits(pkt), rng)
+        if i % 3 == 1:
+            for _ in range(25):
+                sym += [(1, float(rng.integers(100, 1400))), (0, float(rng.integers(100, 1400)))]
+        sym += [(0, float(rng.integers(2000, 30000)))]
+    env = np.concatenate([synth.envelope(sym, rate, lead_in_us=3000.0), np.zeros(2000, np.uint8)]).astype(np.int8)
+    assert env.size > 128 * 1024
+    o = odec.TS33CStreamDecoder(sample_rate=rate)
+    o.work([env])
+    recs = {}
+    for mode in ("pieces", "walk"):
+        if mode == "walk":
+            monkeypatch.setenv("SDR_NO_PIECES", "1")
+        for max_frames in (64, 5):
+            with chain.Chain(rate, decoder=chain.DEC_TS33C, decoder_rate=rate, max_samples=env.size,
+                             max_frames=max_frames) as c:
+                try:
+                    c.process_bits(env)
+                    frames = [_copy(f) for f in c.fetch_frames()]
+                    err = None
+                except _lib.SdrError as ex:      # the overflow is reported when the frames are fetched
+                    err, frames = str(ex), []
+                recs[(mode, max_frames)] = (err, [bytes(bytearray(C.string_at(C.byref(f), C.sizeof(f)))) for f in frames],
+                                            c.decoder_state())
+            if max_frames == 64:
+                assert err is None and len(frames) == len(o.frames) >= 6
+                for of, gf in zip(o.frames, frames):
+                    assert_ts33c_equal(of, gf)
+    assert recs[("pieces", 64)] == recs[("walk", 64)]
+    assert recs[("pieces", 5)] == recs[("walk", 5)] and recs[("pieces", 5)][0] is not None
