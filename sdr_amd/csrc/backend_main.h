@@ -289,12 +289,21 @@ __global__ void __launch_bounds__(BK_THREADS, 6) k_backend(BackParams P)
                 const int n_s = sc[sg];
                 const long long o_s = 1 + s_cnt[sg];
                 const int32_t* from = src + (long long)sg * P.seg_bytes;
-                for (int i = lane; i < n_s; i += 64) {
-                    const long long w = o_s + i;
-                    if (w < P.runs_cap) {
-                        const int32_t at = from[i];
-                        pos[w] = at;
-                        if (w < 2048) s_pos[w] = at;
+                for (int i0 = 0; i0 < n_s; i0 += 256) {   // four loads in flight per lane
+                    int32_t at[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int i = i0 + 64 * u + lane;
+                        at[u] = i < n_s ? from[i] : 0;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int i = i0 + 64 * u + lane;
+                        const long long w = o_s + i;
+                        if (i < n_s && w < P.runs_cap) {
+                            pos[w] = at[u];
+                            if (w < 2048) s_pos[w] = at[u];
+                        }
                     }
                 }
             }

@@ -319,43 +319,47 @@ __device__ inline void wave_stream_decode(const BackParams& P, int cap, WF W, co
     }
     const int cur_type = first_level;
     st->chunk_id += 1;
-    long long n_over = 0;
-    for (long long k0 = 0; k0 < R; k0 += 64) {
-        const long long k = k0 + lane;
-        n_over += __builtin_popcountll(__ballot(k < R && W(k) > reset_limit));
+    // One pass over the run widths (four blocks of 64 per step, so that their loads overlap): the number
+    // of over-limit widths and -- long rows (P.pieces_hdr) -- the run index behind each of them, left in
+    // pieces_b.  Every piece that both starts behind and ends with an over-limit width is a packet of its
+    // own (the piece before it has left no pending symbols), so on long rows only the first and the last
+    // piece are walked here and the pieces in between go to k_decode_pieces, one wavefront each; a middle
+    // piece longer than the pending-symbol table keeps the row on the sequential walk (its overflow
+    // semantics).
+    long long n_over = 0, last_b = 0, nf_mid = 0;
+    bool too_long = false;
+    int32_t* pb = P.pieces_hdr ? P.pieces_b + (long long)cap * P.bits_stride : nullptr;
+    for (long long k00 = 0; k00 < R; k00 += 256) {
+        bool ov[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long long k = k00 + 64 * u + lane;
+            ov[u] = k < R && W(k) > reset_limit;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long long k0 = k00 + 64 * u, k = k0 + lane;
+            const bool over = ov[u];
+            const unsigned long long m = __ballot(over);
+            if (!m) continue;
+            if (pb) {
+                const unsigned long long below = m & lanemask_lt();
+                const long long prev = below ? k0 + (63 - __builtin_clzll(below)) + 1 : last_b;
+                const long long idx = n_over + __builtin_popcountll(below);   // piece number this width closes
+                const long long len = k + 1 - prev;
+                if (over) pb[idx] = (int32_t)(k + 1);
+                too_long = too_long || __ballot(over && idx >= 1 && len > SDR_CUR_CAP) != 0;
+                nf_mid += __builtin_popcountll(__ballot(over && idx >= 1 && len >= 2));
+                last_b = k0 + (63 - __builtin_clzll(m)) + 1;
+            }
+            n_over += __builtin_popcountll(m);
+        }
     }
     const long long npieces = n_over + 1;
     const bool size_is_1 = (npieces == 1 && R == 1);
     if (npieces > 1) st->state = 1;
     double* cur = L.cur;
-    // Long rows (P.pieces_hdr): every piece that both starts behind and ends with an over-limit width is
-    // a packet of its own -- the piece before it has left no pending symbols -- so only the first and the
-    // last piece are walked here and the pieces in between go to k_decode_pieces, one wavefront each.
-    // Their bounds (run index behind each over-limit width) are left in pieces_b; a middle piece longer
-    // than the pending-symbol table keeps the row on the sequential path (its overflow semantics).
-    bool delegate = false;
-    long long last_b = 0, nf_mid = 0;
-    if (P.pieces_hdr && npieces >= 4) {
-        int32_t* pb = P.pieces_b + (long long)cap * P.bits_stride;
-        long long base = 0;
-        bool too_long = false;
-        for (long long k0 = 0; k0 < R; k0 += 64) {
-            const long long k = k0 + lane;
-            const bool over = k < R && W(k) > reset_limit;
-            const unsigned long long m = __ballot(over);
-            if (!m) continue;
-            const unsigned long long below = m & lanemask_lt();
-            const long long prev = below ? k0 + (63 - __builtin_clzll(below)) + 1 : last_b;
-            const long long idx = base + __builtin_popcountll(below);      // piece number this width closes
-            const long long len = k + 1 - prev;
-            if (over) pb[idx] = (int32_t)(k + 1);
-            too_long = too_long || __ballot(over && idx >= 1 && len > SDR_CUR_CAP) != 0;
-            nf_mid += __builtin_popcountll(__ballot(over && idx >= 1 && len >= 2));
-            base += __builtin_popcountll(m);
-            last_b = k0 + (63 - __builtin_clzll(m)) + 1;
-        }
-        delegate = !too_long;
-    }
+    bool delegate = pb && npieces >= 4 && !too_long;
     long long a = 0;
     for (long long pc = 0; pc < npieces; ++pc) {
         if (delegate && pc == 1) {

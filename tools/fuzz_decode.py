@@ -41,7 +41,7 @@ def one(rng, k):
     ncut = int(rng.choice([0, 1, 3, 12]))
     cuts = np.sort(rng.integers(0, env.size + 1, ncut))
     frames = []
-    with chain.Chain(rate, decoder=dec, decoder_rate=rate, max_samples=env.size, max_frames=64) as c:
+    with chain.Chain(rate, decoder=dec, decoder_rate=rate, max_samples=env.size, max_frames=2048) as c:
         for a, e in zip(np.r_[0, cuts], np.r_[cuts, env.size]):
             ch = env[a:e]
             try:
