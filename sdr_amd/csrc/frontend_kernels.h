@@ -288,6 +288,41 @@ __device__ __forceinline__ void frontend_tile(const FrontParams& P, const FrontK
             // the fmas: no VGPR, no v_readlane, no LDS traffic for taps.
             const int nt = P.ntaps;
             int j = 0;
+            if (cplx && !(P.D & 1)) {
+                // Even decimation: every lane's window starts at the same parity, so the samples can be
+                // read two at a time as 16-B words (after one single tap when the tile starts odd).
+                // ds_read_b128 is served in groups of 16 lanes with 4-dword granules: a lane stride of
+                // 2*D dwords with D = 2 (mod 4) -- 10, 50 -- is conflict-free there, while the 8-B
+                // reads of a 32-lane group leave half the banks idle (2-way conflicts).
+                if (lsh & 1) {
+                    const float2 s0 = p[0];
+                    const float a = KT.t[0].x, b = KT.t[0].y;
+                    ar = __builtin_fmaf(a, s0.x, ar);
+                    ar = __builtin_fmaf(-b, s0.y, ar);
+                    ai = __builtin_fmaf(a, s0.y, ai);
+                    ai = __builtin_fmaf(b, s0.x, ai);
+                    j = 1;
+                }
+                for (; j + 8 <= nt; j += 8) {
+                    const float4* p4 = reinterpret_cast<const float4*>(p + j);
+                    float4 qv[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) qv[u] = p4[u];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const float a0 = KT.t[j + 2 * u].x, b0 = KT.t[j + 2 * u].y;
+                        ar = __builtin_fmaf(a0, qv[u].x, ar);
+                        ar = __builtin_fmaf(-b0, qv[u].y, ar);
+                        ai = __builtin_fmaf(a0, qv[u].y, ai);
+                        ai = __builtin_fmaf(b0, qv[u].x, ai);
+                        const float a1 = KT.t[j + 2 * u + 1].x, b1 = KT.t[j + 2 * u + 1].y;
+                        ar = __builtin_fmaf(a1, qv[u].z, ar);
+                        ar = __builtin_fmaf(-b1, qv[u].w, ar);
+                        ai = __builtin_fmaf(a1, qv[u].w, ai);
+                        ai = __builtin_fmaf(b1, qv[u].z, ai);
+                    }
+                }
+            }
             if (cplx) {
                 for (; j + 8 <= nt; j += 8) {
                     float2 s[8];
@@ -311,6 +346,28 @@ __device__ __forceinline__ void frontend_tile(const FrontParams& P, const FrontK
                     ai = __builtin_fmaf(b, s.x, ai);
                 }
             } else {
+                if (!(P.D & 1)) {   // real taps, even decimation: the same 16-B reads
+                    if (lsh & 1) {
+                        const float2 s0 = p[0];
+                        ar = __builtin_fmaf(KT.t[0].x, s0.x, ar);
+                        ai = __builtin_fmaf(KT.t[0].x, s0.y, ai);
+                        j = 1;
+                    }
+                    for (; j + 8 <= nt; j += 8) {
+                        const float4* p4 = reinterpret_cast<const float4*>(p + j);
+                        float4 qv[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) qv[u] = p4[u];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const float a0 = KT.t[j + 2 * u].x, a1 = KT.t[j + 2 * u + 1].x;
+                            ar = __builtin_fmaf(a0, qv[u].x, ar);
+                            ai = __builtin_fmaf(a0, qv[u].y, ai);
+                            ar = __builtin_fmaf(a1, qv[u].z, ar);
+                            ai = __builtin_fmaf(a1, qv[u].w, ai);
+                        }
+                    }
+                }
                 for (; j + 8 <= nt; j += 8) {
                     float2 s[8];
 #pragma unroll
