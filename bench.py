@@ -549,7 +549,7 @@ def pmc_traffic(kernel_key, workload_tag):
     """HBM bytes per launch of one kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
     WRITE_SIZE over this same command; counters cannot be read from inside the process).  None if the
     committed workload differs from the one being run."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_p_pmc.json")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_q_pmc.json")
     try:
         with open(path) as f:
             rec = json.load(f)["kernels"][kernel_key]
@@ -557,7 +557,7 @@ def pmc_traffic(kernel_key, workload_tag):
         return None, None
     if workload_tag not in rec.get("workload", ""):
         return None, None
-    return int(rec["hbm_bytes"]), "profiles/r01_p_pmc.json"
+    return int(rec["hbm_bytes"]), "profiles/r01_q_pmc.json"
 
 
 def main():
