@@ -560,6 +560,75 @@ def pmc_traffic(kernel_key, workload_tag):
     return int(rec["hbm_bytes"]), "profiles/r01_q_pmc.json"
 
 
+def launch_ranks(n, argv, rehearsal):
+    """`python3 bench.py --gpus N` outside torchrun: start N fresh child processes, one per GPU, with the
+    torchrun environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*), BEFORE this process makes any GPU
+    call (torch.cuda.device_count() does not initialise the runtime).  Rank 0 prints the JSON line on the
+    inherited stdout.  Returns the exit code: non-zero if any rank failed (the others are then stopped)."""
+    import socket
+    import subprocess
+    if not rehearsal:
+        import torch
+        have = torch.cuda.device_count()
+        if have < n:
+            sys.stderr.write("bench.py --gpus %d needs %d GPUs, this machine shows %d\n" % (n, n, have))
+            return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    rc = 0
+    alive = list(procs)
+    while alive:
+        for p in list(alive):
+            code = p.poll()
+            if code is None:
+                continue
+            alive.remove(p)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                sys.stderr.write("bench.py: rank %d exited with %d; stopping the other ranks\n" % (procs.index(p), code))
+                for q in alive:
+                    q.terminate()
+        time.sleep(0.05)
+    return rc
+
+
+def rehearsal_main(args, rank, world):
+    """SDR_BENCH_REHEARSAL=gloo: the multi-rank skeleton of this file (rendezvous, frame-table gather, barriers,
+    max over ranks, rank 0's line) on CPU ranks with made-up frame tables and NO chain work -- what
+    tests/test_bench_launcher.py drives.  It measures nothing: value is null and the line says so."""
+    import torch
+    import torch.distributed as dist
+    from sdr_amd import dist as sdist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ncap, max_frames = 8, 4
+    rec = torch.full((ncap * max_frames * sdist.FRAME_BYTES,), rank + 1, dtype=torch.uint8)
+    cnt = torch.full((ncap,), 2, dtype=torch.int32)
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        all_rec, all_cnt = sdist.gather_frames(rec, cnt, world)
+    dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if int(all_cnt.sum()) != 2 * ncap * world or not bool(torch.equal(all_rec[rank * rec.numel():(rank + 1) * rec.numel()], rec)):
+        raise SystemExit("rank %d: rehearsal gather wrong" % rank)
+    if rank == 0:
+        print(json.dumps({"metric": "IQ Msps through filter+demod+slice+decode (whole job)", "value": None, "unit": "Msps",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(float(t.item()) / max(args.steps, 1) * 1e3, 4), "higher_is_better": True,
+                          "scaling": "weak", "vs_baseline": None, "rehearsal": "gloo ranks on CPU, no chain work, nothing measured"}))
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -568,6 +637,16 @@ def main():
     ap.add_argument("--captures", type=int, default=1250, help="captures per GPU (configs[3]: 10000 / 8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    rehearsal = os.environ.get("SDR_BENCH_REHEARSAL") == "gloo"
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            sys.exit(launch_ranks(args.gpus, sys.argv[1:], rehearsal))
+    elif int(os.environ["WORLD_SIZE"]) != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%s ranks" % (args.gpus, os.environ["WORLD_SIZE"]))
+    if rehearsal:
+        return rehearsal_main(args, int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")))
 
     import torch
     import torch.distributed as dist

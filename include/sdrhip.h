@@ -152,7 +152,9 @@ SDR_API int sdr_destroy(sdr_handle* h);
 /* channel-filter taps; n real floats, or n (re,im) pairs when is_complex.
  * Default after sdr_create is the single tap 1 (ref: `taps 1` in
  * FM-Radio/FM-Radio.grc:615-671).  With center_freq != 0 the taps are
- * translated as freq_xlating_fir_filter_ccc does. */
+ * translated as freq_xlating_fir_filter_ccc does.  Setting taps (channel or
+ * post-demod filter) RESTARTS the stream: history, sample counters, keep_one_in_n
+ * counter, threshold and decoder state return to their initial values. */
 SDR_API int sdr_set_taps(sdr_handle* h, const float* taps, int n, int is_complex);
 SDR_API int sdr_set_post_taps(sdr_handle* h, const float* taps, int n);
 /* An upstream channel-filter stage (fir_filter_ccf, real taps, decimation `decim`)
@@ -244,6 +246,31 @@ SDR_API int sdr_profile_read(sdr_handle* h, float* front_ms, float* back_ms, int
  * reference (it has no multi-device path); serves BASELINE.json configs[3]. */
 SDR_API int sdr_export_frames(sdr_handle* h, void* frames_dev, size_t frames_bytes, void* counts_dev,
                               size_t counts_bytes);
+
+/* ---- allocation-free batch entry point ----------------------------------------
+ * No counterpart in the reference.  For callers that cannot allocate device memory
+ * (code under HIP graph capture, tight serving loops, harnesses that forbid
+ * hipMalloc): sdr_batch_process for device-resident input with every OUTPUT in
+ * caller-owned device buffers and every intermediate table (sliced rows, tile
+ * summaries, run tables, pending symbols, decoder states, frame table) in one
+ * file-scope device array of sdr_static_scratch_bytes() = 8 MiB per GPU (held by
+ * each GPU the library runs on until the process ends).  The call performs no
+ * hipMalloc / hipFree and no host synchronisation; work is queued on the handle's
+ * stream.  Same kernels and results as sdr_batch_process + sdr_export_bits /
+ * sdr_export_frames: bits_dev receives n_captures dense rows of out->n_bits sliced
+ * bytes, frames_dev n_captures*cfg.max_frames records (unused slots zeroed),
+ * counts_dev n_captures frame counts.  bits_cap in bytes, frames_cap in records.
+ * Limits: plain chains only (channel filter -> MAG2/QUAD -> slicer -> decoder; no
+ * prefilter, squelch, post-demod filter, channelizer, demod tap); the batch's
+ * tables must fit the static array (about 60 KiB per capture of 2^18 samples at
+ * decimation 50) and a row must stay below 128 KiB of sliced bytes, else
+ * SDR_E_CAPACITY.  All calls on one GPU share that GPU's array: calls that overlap
+ * on one GPU (different handles / streams) race -- serialise them.  The handle's
+ * own results (sdr_fetch_*) are left as they were. */
+SDR_API int sdr_batch_process_static(sdr_handle* h, const void* iq_dev, size_t n_per_capture, size_t stride,
+                                     int n_captures, int8_t* bits_dev, size_t bits_cap, sdr_frame* frames_dev,
+                                     size_t frames_cap, int32_t* counts_dev, sdr_out* out);
+SDR_API size_t sdr_static_scratch_bytes(void);
 
 /* ---- one long capture in contiguous segments (BASELINE.json north_star: "each
  * GPU gets a contiguous segment with FIR-history overlap") ----------------------

@@ -153,6 +153,7 @@ EXPORTS = [
     "sdr_fm_create", "sdr_fm_destroy", "sdr_fm_set_stream", "sdr_fm_process", "sdr_fm_fetch",
     "sdr_fm_last_error",
     "sdr_pfb_create", "sdr_redecode", "sdr_set_input_format", "sdr_history_len", "sdr_seek", "sdr_segment_info_get", "sdr_export_bits",
+    "sdr_batch_process_static", "sdr_static_scratch_bytes",
 ]
 
 _lib = None
@@ -258,6 +259,11 @@ def load():
     L.sdr_segment_info_get.argtypes = [H, C.POINTER(SegmentInfo)]
     L.sdr_export_bits.restype = C.c_int
     L.sdr_export_bits.argtypes = [H, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.sdr_batch_process_static.restype = C.c_int
+    L.sdr_batch_process_static.argtypes = [H, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t,
+                                           C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(Out)]
+    L.sdr_static_scratch_bytes.restype = C.c_size_t
+    L.sdr_static_scratch_bytes.argtypes = []
     L.sdr_fm_create.restype = C.c_int
     L.sdr_fm_create.argtypes = [C.POINTER(FmCfg), C.POINTER(H)]
     L.sdr_fm_destroy.restype = C.c_int

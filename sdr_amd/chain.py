@@ -202,6 +202,24 @@ class Chain(object):
         _lib.check(self._h, self._L.sdr_batch_process(self._h, C.c_void_p(ptr), n, n, ncap, dev, C.byref(self.out)))
         return self.out
 
+    def batch_process_static(self, iq, bits_out, frames_out, counts_out):
+        """sdr_batch_process_static: the allocation-free variant.  All four arguments are torch tensors on
+        this GPU: iq as for batch_process, bits_out uint8/int8 [>= ncap*n_bits], frames_out uint8
+        [>= ncap*max_frames*96], counts_out int32 [>= ncap]."""
+        if not (_is_torch(iq) and iq.is_cuda and iq.is_contiguous()):
+            raise ValueError("batch_process_static takes a contiguous tensor in device memory")
+        ncap, n = int(iq.shape[0]), int(iq.shape[1])
+        if self._cu8 and iq.dim() == 2:
+            n //= 2
+        if counts_out.numel() < ncap:
+            raise ValueError("counts_out too small")
+        _lib.check(self._h, self._L.sdr_batch_process_static(
+            self._h, C.c_void_p(iq.data_ptr()), n, n, ncap, C.c_void_p(bits_out.data_ptr()),
+            bits_out.numel() * bits_out.element_size(), C.c_void_p(frames_out.data_ptr()),
+            frames_out.numel() * frames_out.element_size() // C.sizeof(_lib.Frame), C.c_void_p(counts_out.data_ptr()),
+            C.byref(self.out)))
+        return self.out
+
     # -- results
     def fetch_frames(self):
         n = C.c_size_t()

@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -96,6 +97,10 @@ struct sdr_handle {
     int pipe_mode = 1;   // k_frontend_pipe: 0 never, 1 for cu8 input (default), 2 for complex64 too (env SDR_PIPE; measured slower there)
     int pipe_tpw = 1;    // tiles per workgroup in that kernel (env SDR_TPW); measured on cu8: 1 -> 0.353 ms, 2 -> 0.414, 4 -> 0.447, 8 -> 0.543
     int front_mode = 0;  // 0 auto, 1 LDS/VALU kernel only, 2 MFMA kernel whenever it fits (env SDR_FRONTEND=auto|valu|mfma)
+    // ablation switches (env SDR_NO_KTAPS / SDR_NO_RAW8 / SDR_NO_REUSE / SDR_NO_SEG / SDR_NO_PIECES, SDR_TILE):
+    // read ONCE in sdr_create, never on the call path
+    bool no_ktaps = false, no_raw8 = false, no_reuse = false, no_seg = false, no_pieces = false;
+    int tile_override = 0;
 
     // internal modes used by the FM chain (fm_host.h)
     bool prerotate = false;   // center_freq applies to the INPUT samples (xlating taps=[1] then FIR)
@@ -323,7 +328,7 @@ static int upload_taps(sdr_handle* h)
     }
     memset(&h->ktaps, 0, sizeof h->ktaps);
     h->ktaps_n = 0;
-    if (n <= SDR_KTAPS && !getenv("SDR_NO_KTAPS")) {
+    if (n <= SDR_KTAPS && !h->no_ktaps) {
         for (int k = 0; k < n; ++k) {
             h->ktaps.t[k].x = h->rt_complex ? rt[2 * k] : rt[k];
             h->ktaps.t[k].y = h->rt_complex ? rt[2 * k + 1] : 0.0f;
@@ -366,8 +371,8 @@ static void pick_tile(const sdr_handle* h, int& T, size_t& lds, bool& use_lds)
     use_lds = true;
     // +2: 16-B aligned tile start
     auto bytes = [&](int t) { return ((size_t)(t - 1) * D + nt + 2) * sizeof(float2); };
-    if (const char* e = getenv("SDR_TILE")) {  // tuning override: 64 | 128 | 256
-        T = atoi(e);
+    if (h->tile_override) {  // tuning override: 64 | 128 | 256
+        T = h->tile_override;
         lds = bytes(T);
         if ((T == 64 || T == 128 || T == 256) && lds <= 60 * 1024) return;
     }
@@ -413,6 +418,7 @@ static bool pick_mfma(const sdr_handle* h, int& T, size_t& lds)
 }
 
 static int pfb_upload_taps(sdr_handle* h);
+static int scratch_init(sdr_handle* h);
 
 // ------------------------------------------------------------------ create
 extern "C" int sdr_version(void) { return 101; }
@@ -466,6 +472,9 @@ extern "C" int sdr_create(const sdr_chain_cfg* cfg, sdr_handle** out)
         !(cfg->sample_rate > 0) || cfg->demod < SDR_DEMOD_NONE || cfg->demod > SDR_DEMOD_QUAD ||
         cfg->decoder < SDR_DEC_NONE || cfg->decoder > SDR_DEC_VELUX || cfg->post_ntaps < 0)
         return fail(nullptr, SDR_E_ARG, "sdr_create: bad configuration");
+    if (cfg->max_samples / (uint64_t)cfg->decim >= 0x7fffffffull - 1024ull)
+        return fail(nullptr, SDR_E_CAPACITY, "sdr_create: max_samples/decim must stay below 2^31 filter outputs per capture or call "
+                                             "(tile summaries and run tables index them with 32 bits); cut the capture into segments (sdr_seek)");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
         return fail(nullptr, SDR_E_NODEVICE, "sdr_create: no HIP device (this library has no CPU path)");
@@ -480,6 +489,12 @@ extern "C" int sdr_create(const sdr_chain_cfg* cfg, sdr_handle** out)
         h->front_mode = !strcmp(fm, "valu") ? 1 : (!strcmp(fm, "mfma") ? 2 : 0);
     if (const char* pe = getenv("SDR_PIPE")) h->pipe_mode = atoi(pe);
     if (const char* pe = getenv("SDR_TPW")) h->pipe_tpw = atoi(pe) > 0 ? atoi(pe) : 1;
+    h->no_ktaps = getenv("SDR_NO_KTAPS") != nullptr;
+    h->no_raw8 = getenv("SDR_NO_RAW8") != nullptr;
+    h->no_reuse = getenv("SDR_NO_REUSE") != nullptr;
+    h->no_seg = getenv("SDR_NO_SEG") != nullptr;
+    h->no_pieces = getenv("SDR_NO_PIECES") != nullptr;
+    if (const char* te = getenv("SDR_TILE")) h->tile_override = atoi(te);
     (void)hipDeviceGetAttribute(&h->num_cus, hipDeviceAttributeMultiprocessorCount, h->device);
     if (h->num_cus < 1) h->num_cus = 256;
     int rc = SDR_OK;
@@ -548,7 +563,7 @@ extern "C" int sdr_create(const sdr_chain_cfg* cfg, sdr_handle** out)
         // the record has 4 bytes of alignment padding no field assignment reaches: keep them defined
         HIPCHK(h, hipMemset(h->d_frames, 0, (size_t)(B * h->cfg.max_frames) * sizeof(sdr_frame)));
         h->keep_ctr = h->cfg.keep_n;
-        return SDR_OK;
+        return scratch_init(h);
     };
     rc = body();
     if (rc != SDR_OK) {
@@ -560,6 +575,15 @@ extern "C" int sdr_create(const sdr_chain_cfg* cfg, sdr_handle** out)
     return SDR_OK;
 }
 
+static void reset_stream_counters(sdr_handle* h)
+{
+    h->in_count = h->out_count = 0;
+    h->keep_ctr = h->cfg.keep_n;
+    h->raw_n = 0;
+    h->last_ncap = 0;
+    h->last_nb = h->last_nout = h->last_bits_off = 0;
+}
+
 extern "C" int sdr_set_taps(sdr_handle* h, const float* taps, int n, int is_complex)
 {
     if (!h || !taps || n < 1 || n > 65536) return fail(h, SDR_E_ARG, "sdr_set_taps: bad argument");
@@ -569,7 +593,12 @@ extern "C" int sdr_set_taps(sdr_handle* h, const float* taps, int n, int is_comp
     h->proto_complex = is_complex != 0;
     h->ntaps = n;
     if (h->pfb_M) return pfb_upload_taps(h);
-    return upload_taps(h);
+    // new taps restart the stream (history zeroed by upload_taps, counters and decoder state here):
+    // a history of zero BYTES would not be the zeros before stream start for cu8 input
+    int r = upload_taps(h);
+    if (r) return r;
+    reset_stream_counters(h);
+    return reset_dec_state(h);
 }
 
 extern "C" int sdr_set_post_taps(sdr_handle* h, const float* taps, int n)
@@ -586,7 +615,8 @@ extern "C" int sdr_set_post_taps(sdr_handle* h, const float* taps, int n)
     }
     HIPCHK(h, hipMemcpy(h->d_post_rtaps, rt.data(), n * sizeof(float), hipMemcpyHostToDevice));
     h->post_taps.assign(taps, taps + n);
-    return SDR_OK;
+    reset_stream_counters(h);   // as sdr_set_taps: the stream restarts
+    return reset_dec_state(h);
 }
 
 extern "C" int sdr_set_prefilter(sdr_handle* h, const float* taps, int n, int decim)
@@ -624,15 +654,6 @@ extern "C" int sdr_set_prefilter(sdr_handle* h, const float* taps, int n, int de
     h->in_fmt = SDR_IN_FC32;
     h->pre = p;
     return SDR_OK;
-}
-
-static void reset_stream_counters(sdr_handle* h)
-{
-    h->in_count = h->out_count = 0;
-    h->keep_ctr = h->cfg.keep_n;
-    h->raw_n = 0;
-    h->last_ncap = 0;
-    h->last_nb = h->last_nout = h->last_bits_off = 0;
 }
 
 extern "C" int sdr_set_input_format(sdr_handle* h, int fmt)
@@ -792,7 +813,7 @@ static int launch_front(sdr_handle* h, const float2* x, long long stride, long l
     dim3 grid(g.tiles, ncap), block(g.T);
     if (g.mfma)
         hipLaunchKernelGGL(k_frontend_mfma, grid, block, g.lds, h->stream, P);
-    else if (h->in_fmt == SDR_IN_CU8 && P.vec_ok && !P.pre_tab && P.ktaps_n > 0 && g.use_lds && !getenv("SDR_NO_RAW8")) {
+    else if (h->in_fmt == SDR_IN_CU8 && P.vec_ok && !P.pre_tab && P.ktaps_n > 0 && g.use_lds && !h->no_raw8) {
         // bytes stay bytes in LDS: (count + up to 7 samples of alignment) rounded up to 16-B chunks
         const long long count = (long long)(g.T - 1) * c.decim + h->ntaps;
         const size_t lds = (size_t)((count + 7 + 7) / 8) * 16;
@@ -968,11 +989,11 @@ static int launch_back(sdr_handle* h, int ncap, const CallGeom& g, long long pat
     Bp.log2n = h->d_log2;
     Bp.runs_n = h->d_runs_n;
     const bool full_pass = run_decoder && c.decoder != SDR_DEC_NONE && !Bp.nout_var;
-    if (h->reuse_next && h->runs_valid && full_pass && !getenv("SDR_NO_REUSE")) {
+    if (h->reuse_next && h->runs_valid && full_pass && !h->no_reuse) {
         Bp.reuse_runs = 1;
         hipLaunchKernelGGL(k_backend, dim3(ncap), dim3(BK_THREADS), 0, h->stream, Bp);
     } else if (h->d_runs_seg && !Bp.nout_var && run_decoder && c.decoder != SDR_DEC_NONE && nb_total >= SDR_SEG_MIN_ROW &&
-        !getenv("SDR_NO_SEG")) {
+        !h->no_seg) {
         // long rows: carries first (they patch the bytes), then the run starts of every 64-KiB-or-more
         // segment by its own workgroup, then the decoders on the gathered run table
         const long long round = BK_THREADS * 64;
@@ -988,7 +1009,7 @@ static int launch_back(sdr_handle* h, int ncap, const CallGeom& g, long long pat
         Bp.phase_sel = 2;
         Bp.tsum = nullptr;
         Bp.fresh = 0;
-        const bool pieces = is_stream_decoder(c.decoder) && !getenv("SDR_NO_PIECES");
+        const bool pieces = is_stream_decoder(c.decoder) && !h->no_pieces;
         if (pieces) {
             Bp.pieces_b = h->d_runs_seg;
             Bp.pieces_hdr = h->d_pieces_hdr;
@@ -1544,6 +1565,123 @@ extern "C" int sdr_export_bits(sdr_handle* h, void* bits_dev, size_t cap_bytes, 
                        (size_t)h->bits_stride, width, rows, (unsigned char*)bits_dev);
     HIPCHK(h, hipGetLastError());
     return SDR_OK;
+}
+
+// ------------------------------------------------------------------ allocation-free batch entry point
+// sdr_batch_process_static: sdr_batch_process for callers that cannot call hipMalloc (HIP graph
+// capture, tight serving loops).  Everything the kernels need beyond the caller's input and output
+// buffers -- sliced rows, tile summaries, run tables, pending symbols, decoder states, frame table --
+// lives in ONE file-scope device array per GPU instead of the handle's hipMalloc'ed buffers.
+// Host code never passes the array's name to a kernel: the device address is looked up once per
+// device (scratch_init, from sdr_create) with hipGetSymbolAddress and kept in g_scratch_ptr.
+#define SDR_STATIC_SCRATCH_BYTES (8u << 20)
+#define SDR_STATIC_MAX_DEVICES 64
+static __device__ __align__(256) unsigned char scratch[SDR_STATIC_SCRATCH_BYTES];
+static unsigned char* g_scratch_ptr[SDR_STATIC_MAX_DEVICES];   // per device: that GPU's copy of the array
+static std::mutex g_scratch_mu;
+
+static int scratch_init(sdr_handle* h)
+{
+    const int dev = h->device;
+    if (dev < 0 || dev >= SDR_STATIC_MAX_DEVICES) return SDR_OK;   // the static entry point refuses such a device
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    if (g_scratch_ptr[dev]) return SDR_OK;
+    void* ptr = nullptr;
+    HIPCHK(h, hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));    // the handle's device is current (sdr_create)
+    if (!ptr) return fail(h, SDR_E_HIP, "hipGetSymbolAddress(scratch) returned a null address");
+    g_scratch_ptr[dev] = static_cast<unsigned char*>(ptr);
+    return SDR_OK;
+}
+
+extern "C" size_t sdr_static_scratch_bytes(void) { return SDR_STATIC_SCRATCH_BYTES; }
+
+extern "C" int sdr_batch_process_static(sdr_handle* h, const void* iq_dev, size_t n, size_t stride, int ncap,
+                                        int8_t* bits_dev, size_t bits_cap, sdr_frame* frames_dev, size_t frames_cap,
+                                        int32_t* counts_dev, sdr_out* out)
+{
+    if (!h || !iq_dev || ncap < 1 || !bits_dev || !frames_dev || !counts_dev)
+        return fail(h, SDR_E_ARG, "sdr_batch_process_static: null argument (all buffers are caller-owned DEVICE memory)");
+    if (h->pfb_M || h->pre || h->squelch_on || h->cfg.post_ntaps > 0 || h->prerotate || h->skip_slice ||
+        h->cfg.demod == SDR_DEMOD_NONE || h->cfg.tap_demod)
+        return fail(h, SDR_E_ARG, "sdr_batch_process_static: plain chains only (channel filter -> MAG2/QUAD -> slicer -> decoder; "
+                                  "no prefilter, squelch, post-demod filter, channelizer or demod tap)");
+    if (stride < n) return fail(h, SDR_E_ARG, "sdr_batch_process_static: stride < n_per_capture");
+    if (h->device < 0 || h->device >= SDR_STATIC_MAX_DEVICES || !g_scratch_ptr[h->device])
+        return fail(h, SDR_E_HIP, "sdr_batch_process_static: no static scratch address for this device");
+    (void)hipSetDevice(h->device);
+    const sdr_chain_cfg& c = h->cfg;
+    CallGeom g;
+    fill_geom(h, (long long)(n / c.decim), 0, c.keep_n - 1, g, false);
+    if (g.nout >= 0x7fffffffLL - 1024) return fail(h, SDR_E_CAPACITY, "sdr_batch_process_static: more than 2^31 filter outputs per capture");
+    // carve this call's tables out of the device's static array (256-B aligned pieces)
+    const long long B = ncap;
+    const long long bstride = ((g.ne + 63) / 64 + 1) * 64;
+    const long long rcap = bstride;
+    size_t off = 0;
+    auto carve = [&](size_t bytes) {
+        const size_t at = off;
+        off = (off + bytes + 255) & ~(size_t)255;
+        return at;
+    };
+    const size_t o_bits = carve((size_t)(B * bstride));
+    const size_t o_tsum = carve((size_t)(B * (g.tiles + 1)) * sizeof(TileSum));
+    const size_t o_runs = carve((size_t)(B * (rcap + 2)) * sizeof(int32_t));
+    const size_t o_runs_n = carve((size_t)B * sizeof(int32_t));
+    const size_t o_cur = carve((size_t)(B * SDR_CUR_CAP) * sizeof(double));
+    const size_t o_st = carve((size_t)B * sizeof(DecState));
+    const size_t o_frames = carve((size_t)(B * c.max_frames) * sizeof(sdr_frame));
+    if (off > SDR_STATIC_SCRATCH_BYTES || bstride >= SDR_SEG_MIN_ROW)
+        return fail(h, SDR_E_CAPACITY, "sdr_batch_process_static: this batch needs " + std::to_string(off) + " bytes of scratch, the static array holds " +
+                                       std::to_string(SDR_STATIC_SCRATCH_BYTES) + " (and rows must stay below 128 KiB of sliced bytes); use sdr_batch_process");
+    if (bits_cap < (size_t)(B * g.ne) || frames_cap < (size_t)(B * c.max_frames))
+        return fail(h, SDR_E_CAPACITY, "sdr_batch_process_static: output buffer too small");
+    unsigned char* const base = g_scratch_ptr[h->device];   // never the array's name: that is a host-side stand-in
+    // what must start at zero: row padding behind the sliced bytes, the frame table (record padding bytes)
+    HIPCHK(h, hipMemsetAsync(base + o_bits, 0, (size_t)(B * bstride), h->stream));
+    HIPCHK(h, hipMemsetAsync(base + o_frames, 0, (size_t)(B * c.max_frames) * sizeof(sdr_frame), h->stream));
+    // run the handle's own launch path on the static tables
+    struct Saved {
+        int8_t* bits; long long bstride; TileSum* tsum; int tstride; int32_t *runs, *runs_seg, *runs_n; long long rcap;
+        double* cur; DecState* st; sdr_frame* frames; unsigned long long out_count; bool profile;
+    } sv{h->d_bits, h->bits_stride, h->d_tsum, h->tsum_stride, h->d_runs, h->d_runs_seg, h->d_runs_n, h->runs_cap,
+         h->d_cur, h->d_st, h->d_frames, h->out_count, h->profile};
+    h->d_bits = reinterpret_cast<int8_t*>(base + o_bits);
+    h->bits_stride = bstride;
+    h->d_tsum = reinterpret_cast<TileSum*>(base + o_tsum);
+    h->tsum_stride = g.tiles + 1;
+    h->d_runs = reinterpret_cast<int32_t*>(base + o_runs);
+    h->d_runs_seg = nullptr;
+    h->d_runs_n = reinterpret_cast<int32_t*>(base + o_runs_n);
+    h->runs_cap = rcap;
+    h->d_cur = reinterpret_cast<double*>(base + o_cur);
+    h->d_st = reinterpret_cast<DecState*>(base + o_st);
+    h->d_frames = reinterpret_cast<sdr_frame*>(base + o_frames);
+    h->out_count = 0;
+    h->profile = false;
+    int run = 1;
+    if (is_stream_decoder(c.decoder))
+        run = ((double)g.ne * 1e6 / h->dec_rate > decoder_reset_limit(c.decoder)) ? 1 : 0;
+    int r = launch_front_and_back(h, (const float2*)iq_dev, (long long)stride, (long long)n, ncap, nullptr, 0, g, 0, g.ne, 1, 0, run);
+    if (r == SDR_OK && g.ne > 0) {
+        size_t total = (size_t)(B * g.ne), blocks = (total + 255) / 256;
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(k_pack_rows, dim3((unsigned)blocks), dim3(256), 0, h->stream, (const unsigned char*)h->d_bits,
+                           (size_t)bstride, (size_t)g.ne, (size_t)B, (unsigned char*)bits_dev);
+    }
+    if (r == SDR_OK) {
+        long long total = B * c.max_frames * (long long)(sizeof(sdr_frame) / 4);
+        int blocks = (int)((total + 255) / 256);
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(k_export_frames, dim3(blocks), dim3(256), 0, h->stream, h->d_frames, h->d_st, ncap, c.max_frames,
+                           frames_dev, counts_dev);
+    }
+    h->d_bits = sv.bits; h->bits_stride = sv.bstride; h->d_tsum = sv.tsum; h->tsum_stride = sv.tstride;
+    h->d_runs = sv.runs; h->d_runs_seg = sv.runs_seg; h->d_runs_n = sv.runs_n; h->runs_cap = sv.rcap;
+    h->d_cur = sv.cur; h->d_st = sv.st; h->d_frames = sv.frames; h->out_count = sv.out_count; h->profile = sv.profile;
+    h->runs_valid = false;   // the handle's run table does not describe what its next sdr_redecode would expect
+    if (r) return r;
+    HIPCHK(h, hipGetLastError());
+    return finish_out(h, out, (unsigned long long)n * ncap, g.ne);
 }
 
 #include "pfb_host.h"
