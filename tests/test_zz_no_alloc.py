@@ -67,6 +67,9 @@ def test_static_entry_point_matches_batch_process_twice():
         big = torch.zeros((32, 1 << 18, 2), dtype=torch.float32, device=dev)
         with chain.Chain(fs, decim=1, taps=taps, decoder=chain.DEC_TS33C, max_batch=32, max_frames=max_frames,
                          max_samples=1 << 18) as wide:
+            bits = torch.zeros(32 << 18, dtype=torch.uint8, device=dev)
+            rec = torch.zeros(32 * max_frames * C.sizeof(_lib.Frame), dtype=torch.uint8, device=dev)
+            cnt = torch.zeros(32, dtype=torch.int32, device=dev)
             with pytest.raises(_lib.SdrError) as ei:
                 wide.batch_process_static(big, bits, rec, cnt)
             assert ei.value.code == _lib.SDR_E_CAPACITY and "static array" in str(ei.value)
