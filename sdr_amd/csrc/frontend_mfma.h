@@ -28,15 +28,16 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// Hysteresis + slicer for 4 consecutive outputs per thread (see slice_tile).
-__device__ __forceinline__ void slice_tile_x4(const bool* valid, const float* v, long long o_first, long long o_base,
+// Hysteresis + slicer for N consecutive outputs per thread (see slice_tile).
+template <int N>
+__device__ __forceinline__ void slice_tile_xn(const bool* valid, const float* v, long long o_first, long long o_base,
                                               float lo, float hi, int keep_n, long long keep_c0,
                                               int8_t* __restrict__ bits, TileSum* __restrict__ ts_out,
                                               int* __restrict__ sh /* 12 ints */)
 {
-    int evt[4], has = 0, last = 0, firstk = 0;
+    int evt[N], has = 0, last = 0, firstk = 0;
 #pragma unroll
-    for (int e = 3; e >= 0; --e) {
+    for (int e = N - 1; e >= 0; --e) {
         evt[e] = valid[e] ? (v[e] > hi ? 1 : (v[e] < lo ? 2 : 0)) : 0;
         if (evt[e]) {
             if (!has) last = (evt[e] == 1);
@@ -51,7 +52,7 @@ __device__ __forceinline__ void slice_tile_x4(const bool* valid, const float* v,
     if (lane == 0) {
         sh[wave] = any != 0;
         sh[4 + wave] = any ? (int)((sset >> (63 - __builtin_clzll(any))) & 1) : 0;
-        sh[8 + wave] = any ? ((wave * 64 + __builtin_ctzll(any)) * 4 + fk) : -1;
+        sh[8 + wave] = any ? ((wave * 64 + __builtin_ctzll(any)) * N + fk) : -1;
     }
     __syncthreads();
     const unsigned long long below = any & ((1ull << lane) - 1ull);
@@ -76,11 +77,11 @@ __device__ __forceinline__ void slice_tile_x4(const bool* valid, const float* v,
         ts_out->last_state = lst;
     }
     // keep_one_in_n: one division per thread (32-bit when the index allows), then
-    // the remainder is stepped along the thread's 4 outputs
+    // the remainder is stepped along the thread's N outputs
     const long long r0 = o_first - keep_c0;
     long long quo = 0;
     int rem = 0;
-    if (keep_n > 1 && r0 + 3 >= 0) {
+    if (keep_n > 1 && r0 + (N - 1) >= 0) {
         const long long rb = r0 < 0 ? 0 : r0;  // first non-negative index of this thread
         if (rb < 0x7fffffffLL) {
             quo = (unsigned)rb / (unsigned)keep_n;
@@ -91,7 +92,7 @@ __device__ __forceinline__ void slice_tile_x4(const bool* valid, const float* v,
         }
     }
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
+    for (int e = 0; e < N; ++e) {
         if (evt[e] == 1)
             st = 1;
         else if (evt[e] == 2)
@@ -310,6 +311,6 @@ __global__ void __launch_bounds__(256) k_frontend_mfma(FrontParams P)
             if (valid[e]) dst[m0 + e] = v[e];
     }
     if (!P.do_slice) return;
-    slice_tile_x4(valid, v, m0, m_t0, P.lo, P.hi, P.keep_n, P.keep_c0, P.bits + (long long)cap * P.bits_stride,
+    slice_tile_xn<4>(valid, v, m0, m_t0, P.lo, P.hi, P.keep_n, P.keep_c0, P.bits + (long long)cap * P.bits_stride,
                   P.tsum + (long long)cap * P.tiles_per_capture + tile, sh);
 }

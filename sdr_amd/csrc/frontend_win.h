@@ -1,0 +1,213 @@
+// Channel filter at decimation 1 with real taps (fir_filter_ccf as the reference wires it:
+// TFA/decoder.grc:1163-1234 27 taps, FM-Radio/FM-Radio.grc:674-746 33 taps, TS33C/live_decoder.grc:917-988
+// 121 taps) on the vector ALUs with a SLIDING WINDOW: every lane owns WIN_R consecutive outputs and
+// keeps the samples they share in registers, so one LDS read feeds WIN_R packed fmas instead of one.
+//
+//   acc[r] += tap[j] * x[lane*R + r + j]        r = 0..R-1, j ascending (oldest sample first: the
+//                                               oracle's order, one fmaf per tap and component)
+//
+// The window is a ring of WIN_W = R + 6 registers (sample s of the lane sits in slot s mod W); the tap
+// loop is unrolled by W so every slot index is static.  After sub-step u the slots u-1 and u are dead
+// and take the samples W ahead (one aligned 16-B ds_read for two samples, in flight for five
+// sub-steps = 50 packed fmas).  Lane stride = R samples = 5 granules of 16 B: a 16-lane group of a
+// ds_read_b128 touches 16 different granules of the 64 banks -- conflict-free without padding.
+// Taps sit in LDS (broadcast reads, in order with the sample reads on one counter).  A tile that
+// starts on an odd sample is read from one sample earlier with the tap table shifted by one and the
+// dummy first step skipped (no 0*x product is ever formed, so non-finite samples stay local).
+// 4*ntaps/1 flop per input sample against 8 bytes: fp32-FMA bound from ~16 taps up.
+#pragma once
+#include "frontend_mfma.h"
+
+#define WIN_R 10
+#define WIN_W 16
+
+// LDS floats of the tap table (shifted copy + one block of slack), 16-B multiple
+__host__ __device__ inline int win_tap_floats(int ntaps) { return (ntaps + 1 + WIN_W + 3) & ~3; }
+// staged sample positions: T*R outputs + taps rounded up to whole blocks + one block of look-ahead
+__host__ __device__ inline int win_sample_slots(int T, int ntaps)
+{
+    return T * WIN_R + ((ntaps + 1 + WIN_W - 1) / WIN_W) * WIN_W + WIN_W + 2;
+}
+
+// blockDim.x = T (64 or 256), P.D == 1, real taps, P.tile_out = T*WIN_R - q.
+__global__ void __launch_bounds__(256) k_frontend_win(FrontParams P)
+{
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    __shared__ int sh[12];
+    __shared__ float s_atan[257];
+    __shared__ float2 s_edge[4];
+    constexpr int R = WIN_R, W = WIN_W;
+    const int T = blockDim.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int tile = blockIdx.x, cap = blockIdx.y;
+    const int nt = P.ntaps, H = nt - 1;
+    const int q = (P.demod == SDR_DEMOD_QUAD) ? 1 : 0;
+    if (q)
+        for (int i = t; i < 257; i += T) s_atan[i] = P.atan_tab[i];
+    const int ntl = win_tap_floats(nt);
+    float* const tapL = reinterpret_cast<float*>(smem_raw);
+    float2* const lds = reinterpret_cast<float2*>(tapL + ntl);
+
+    const long long o0 = (long long)tile * P.tile_out;
+    const long long m_t0 = o0 - q;                         // FIR output index of thread 0's first output
+    const float2* __restrict__ x = P.x + (long long)cap * P.stride;
+    const long long lo_idx = P.in0 + m_t0 - H;             // first input sample of the tile (D == 1)
+    const int count = T * R + H;
+
+    auto fetch = [&](long long idx) -> float2 {
+        if (idx >= 0) return idx < P.n ? x[idx] : make_float2(0.f, 0.f);
+        if (P.hist && idx >= -(long long)P.hist_len) return P.hist[P.hist_len + idx];
+        return make_float2(0.f, 0.f);
+    };
+    int lsh = 0;   // LDS index of sample lo_idx
+    if (P.vec_ok && !P.pre_tab) {
+        // 16-B chunks inside the capture by DMA (a loop that holds nothing else), the few that touch
+        // its edges by guarded loads -- as k_frontend
+        const long long gidx = (long long)cap * P.stride + lo_idx;
+        const int odd = (int)(gidx & 1);
+        const long long lo_al = lo_idx - odd;
+        const int pairs = (count + odd + 1) >> 1;
+        lsh = odd;
+        for (int p0 = (t & ~63); p0 < pairs; p0 += T) {
+            const int p = p0 + lane;
+            const long long s = lo_al + 2LL * p;
+            if (p < pairs && s >= 0 && s + 2 <= P.n)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(x + s),
+                                                 (__attribute__((address_space(3))) void*)(lds + 2 * p0), 16, 0,
+                                                 SDR_GLDS_AUX);
+        }
+        if (lo_al < 0 || lo_al + 2LL * pairs > P.n) {   // uniform: only edge tiles have guarded chunks
+            for (int p = t; p < pairs; p += T) {
+                const long long s = lo_al + 2LL * p;
+                if (!(s >= 0 && s + 2 <= P.n)) {
+                    lds[2 * p] = fetch(s);
+                    lds[2 * p + 1] = fetch(s + 1);
+                }
+            }
+        }
+    } else {
+        for (int i = t; i < count; i += T) {
+            const long long idx = lo_idx + i;
+            float2 v = fetch(idx);
+            if (P.pre_tab) {   // freq_xlating_fir_filter with taps=[1] in front of the FIR (FM chain)
+                const float2 r = nco_eval(P.pre_tab, (P.pre_idx0 + (unsigned long long)idx) * P.pre_inc);
+                v = make_float2(__builtin_fmaf(v.x, r.x, -(v.y * r.y)), __builtin_fmaf(v.x, r.y, v.y * r.x));
+            }
+            lds[i] = v;
+        }
+    }
+    // tap table, shifted by one when the tile starts odd: tapL[j] = rtaps[j - shift]
+    const int shift = lsh & 1;
+    for (int i = t; i < ntl; i += T) {
+        const int idx = i - shift;
+        tapL[i] = (idx >= 0 && idx < nt) ? P.rtaps[idx] : 0.f;
+    }
+    __syncthreads();
+
+    // ---- sliding-window FIR.  The packed fmas are written out (v_pk_fma_f32: one IEEE fma per
+    // component, the same rounding as two fmaf calls) so that the tap can be taken from either half of
+    // its register pair by op_sel -- the compiler's own selection moved every odd tap and every window
+    // pair into fresh registers first (94 moves per 156 fmas).
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    v2f acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = (v2f){0.f, 0.f};
+    {
+        const v4f* pw = reinterpret_cast<const v4f*>(lds + (lsh - shift) + t * R);   // 16-B aligned: two samples per read
+        const v4f* pt = reinterpret_cast<const v4f*>(tapL);
+        const int jlo = shift, jhi = nt + shift;
+        v2f w[W];
+#pragma unroll
+        for (int k = 0; k < W / 2; ++k) {
+            const v4f v = pw[k];
+            w[2 * k] = v.xy;
+            w[2 * k + 1] = v.zw;
+        }
+#define WIN_FMA_LO(A, TP, X) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(A) : "v"(TP), "v"(X))
+#define WIN_FMA_HI(A, TP, X) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(A) : "v"(TP), "v"(X))
+        for (int j0 = 0; j0 < jhi; j0 += W) {
+            v2f tp[W / 2];   // tap pairs (t[2k], t[2k+1])
+#pragma unroll
+            for (int k = 0; k < W / 4; ++k) {
+                const v4f v = pt[(j0 >> 2) + k];
+                tp[2 * k] = v.xy;
+                tp[2 * k + 1] = v.zw;
+            }
+            const v4f* pn = pw + ((j0 + W) >> 1);
+            const bool full = j0 >= jlo && j0 + W <= jhi;   // uniform
+#pragma unroll
+            for (int u = 0; u < W; ++u) {
+                if (full || (j0 + u >= jlo && j0 + u < jhi)) {
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        if (u & 1)
+                            WIN_FMA_HI(acc[r], tp[u >> 1], w[(u + r) % W]);
+                        else
+                            WIN_FMA_LO(acc[r], tp[u >> 1], w[(u + r) % W]);
+                    }
+                }
+                if (u & 1) {
+                    const v4f v = pn[u >> 1];
+                    w[u - 1] = v.xy;
+                    w[u] = v.zw;
+                }
+            }
+        }
+#undef WIN_FMA_LO
+#undef WIN_FMA_HI
+    }
+
+    // ---- epilogue: thread t owns outputs R*t .. R*t+R-1 of the tile
+    const long long m0 = m_t0 + (long long)R * t;
+    bool valid[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const long long m = m0 + r;
+        const bool have_y = (m >= 0 || P.hist != nullptr) && (m < P.nout);
+        if (!have_y) acc[r] = (v2f){0.f, 0.f};
+        valid[r] = (R * t + r >= q) && (m < P.nout);
+    }
+    if (P.demod == SDR_DEMOD_NONE) {
+        if (P.tap) {
+            float2* dst = reinterpret_cast<float2*>(P.tap + (long long)cap * P.tap_stride);
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if (valid[r]) dst[m0 + r] = make_float2(acc[r].x, acc[r].y);
+        }
+        return;
+    }
+    float v[R];
+    if (P.demod == SDR_DEMOD_MAG2) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) v[r] = __builtin_fmaf(acc[r].x, acc[r].x, acc[r].y * acc[r].y);
+    } else {
+        // the output before the thread's first one belongs to the neighbouring lane (wave)
+        float2 pv;
+        pv.x = __shfl_up(acc[R - 1].x, 1);
+        pv.y = __shfl_up(acc[R - 1].y, 1);
+        if (lane == 63) s_edge[wave] = make_float2(acc[R - 1].x, acc[R - 1].y);
+        __syncthreads();
+        if (lane == 0) pv = wave ? s_edge[wave - 1] : make_float2(0.f, 0.f);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            v[r] = 0.f;
+            const float2 pr = r ? make_float2(acc[r - 1].x, acc[r - 1].y) : pv;
+            if (valid[r]) {
+                const float tr = __builtin_fmaf(acc[r].x, pr.x, acc[r].y * pr.y);
+                const float ti = __builtin_fmaf(acc[r].y, pr.x, -(acc[r].x * pr.y));
+                v[r] = fast_atan2f_dev(s_atan, ti, tr);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) v[r] = P.gain * v[r];
+    if (P.tap) {
+        float* dst = P.tap + (long long)cap * P.tap_stride;
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            if (valid[r]) dst[m0 + r] = v[r];
+    }
+    if (!P.do_slice) return;
+    slice_tile_xn<R>(valid, v, m0, m_t0, P.lo, P.hi, P.keep_n, P.keep_c0, P.bits + (long long)cap * P.bits_stride,
+                     P.tsum + (long long)cap * P.tiles_per_capture + tile, sh);
+}

@@ -13,6 +13,7 @@
 #include "sdr_common.h"
 #include "frontend_kernels.h"
 #include "frontend_mfma.h"
+#include "frontend_win.h"
 #include "backend_kernels.h"
 #include "backend_main.h"
 #include "fm_kernels.h"
@@ -96,7 +97,7 @@ struct sdr_handle {
     size_t ss() const { return in_fmt == SDR_IN_CU8 ? 2 : sizeof(float2); }  // bytes per input sample
     int pipe_mode = 1;   // k_frontend_pipe: 0 never, 1 for cu8 input (default), 2 for complex64 too (env SDR_PIPE; measured slower there)
     int pipe_tpw = 1;    // tiles per workgroup in that kernel (env SDR_TPW); measured on cu8: 1 -> 0.353 ms, 2 -> 0.414, 4 -> 0.447, 8 -> 0.543
-    int front_mode = 0;  // 0 auto, 1 LDS/VALU kernel only, 2 MFMA kernel whenever it fits (env SDR_FRONTEND=auto|valu|mfma)
+    int front_mode = 0;  // 0 auto, 1 LDS/VALU kernel only, 2 MFMA kernel whenever it fits, 3 sliding-window kernel whenever it fits (env SDR_FRONTEND=auto|valu|mfma|win)
     // ablation switches (env SDR_NO_KTAPS / SDR_NO_RAW8 / SDR_NO_REUSE / SDR_NO_SEG / SDR_NO_PIECES, SDR_TILE):
     // read ONCE in sdr_create, never on the call path
     bool no_ktaps = false, no_raw8 = false, no_reuse = false, no_seg = false, no_pieces = false;
@@ -401,9 +402,20 @@ static size_t mfma_lds_bytes(int D, int ntaps, int nw)
 
 // The matrix-core kernel pays when the filter is fp32-FMA bound: real taps and
 // enough flops per input sample that the LDS-walking kernel is not HBM bound.
+// k_frontend_win (frontend_win.h): decimation 1, real taps, complex64 input.  Every lane owns WIN_R
+// consecutive outputs; chosen over the matrix-core form there (measured).
+static bool pick_win(const sdr_handle* h, long long nout, int& T, size_t& lds)
+{
+    if (h->front_mode == 1 || h->front_mode == 2 || h->rt_complex || h->in_fmt != SDR_IN_FC32 || h->cfg.decim != 1) return false;
+    if (h->front_mode == 0 && h->ntaps < 8) return false;
+    T = nout >= 8LL * 256 * WIN_R ? 256 : 64;
+    lds = (size_t)win_tap_floats(h->ntaps) * 4 + (size_t)win_sample_slots(T, h->ntaps) * sizeof(float2);
+    return lds <= 60 * 1024;
+}
+
 static bool pick_mfma(const sdr_handle* h, int& T, size_t& lds)
 {
-    if (h->front_mode == 1 || h->rt_complex || h->in_fmt != SDR_IN_FC32) return false;
+    if (h->front_mode == 1 || h->front_mode == 3 || h->rt_complex || h->in_fmt != SDR_IN_FC32) return false;
     const int D = h->cfg.decim, nt = h->ntaps;
     if (h->front_mode == 0 && 4.0 * nt / D < 24.0) return false;
     for (int nw = 4; nw >= 1; nw >>= 1) {
@@ -486,7 +498,7 @@ extern "C" int sdr_create(const sdr_chain_cfg* cfg, sdr_handle** out)
         return fail(nullptr, SDR_E_HIP, "hipGetDevice failed");
     }
     if (const char* fm = getenv("SDR_FRONTEND"))
-        h->front_mode = !strcmp(fm, "valu") ? 1 : (!strcmp(fm, "mfma") ? 2 : 0);
+        h->front_mode = !strcmp(fm, "valu") ? 1 : (!strcmp(fm, "mfma") ? 2 : (!strcmp(fm, "win") ? 3 : 0));
     if (const char* pe = getenv("SDR_PIPE")) h->pipe_mode = atoi(pe);
     if (const char* pe = getenv("SDR_TPW")) h->pipe_tpw = atoi(pe) > 0 ? atoi(pe) : 1;
     h->no_ktaps = getenv("SDR_NO_KTAPS") != nullptr;
@@ -749,6 +761,7 @@ struct CallGeom {
     size_t lds;
     bool use_lds;
     bool mfma;   // k_frontend_mfma: T = 64*nw threads, 256*nw FIR outputs per tile
+    bool win = false;  // k_frontend_win: T threads, T*WIN_R FIR outputs per tile
     int pipe_nch = 0;  // >0: k_frontend_pipe with this many 16-B chunks per lane per tile
     int pipe_tpw = 0;  // tiles per workgroup
 };
@@ -811,7 +824,9 @@ static int launch_front(sdr_handle* h, const float2* x, long long stride, long l
     } else if (c.demod == SDR_DEMOD_NONE && !h->d_tap)
         return fail(h, SDR_E_ARG, "demod NONE needs cfg.tap_demod (complex output buffer)");
     dim3 grid(g.tiles, ncap), block(g.T);
-    if (g.mfma)
+    if (g.win)
+        hipLaunchKernelGGL(k_frontend_win, grid, block, g.lds, h->stream, P);
+    else if (g.mfma)
         hipLaunchKernelGGL(k_frontend_mfma, grid, block, g.lds, h->stream, P);
     else if (h->in_fmt == SDR_IN_CU8 && P.vec_ok && !P.pre_tab && P.ktaps_n > 0 && g.use_lds && !h->no_raw8) {
         // bytes stay bytes in LDS: (count + up to 7 samples of alignment) rounded up to 16-B chunks
@@ -1037,8 +1052,12 @@ static void fill_geom(const sdr_handle* h, long long nout, long long in0, long l
     const long long kn = h->cfg.keep_n;
     g.ne = nout > keep_c0 ? (nout - keep_c0 + kn - 1) / kn : 0;
     const int q = (h->cfg.demod == SDR_DEMOD_QUAD && !to_squelch) ? 1 : 0;
-    g.mfma = pick_mfma(h, g.T, g.lds);
-    if (g.mfma) {
+    g.win = pick_win(h, nout, g.T, g.lds);
+    g.mfma = !g.win && pick_mfma(h, g.T, g.lds);
+    if (g.win) {
+        g.use_lds = true;
+        g.tile_out = WIN_R * g.T - q;
+    } else if (g.mfma) {
         g.use_lds = true;
         g.tile_out = 4 * g.T - q;
     } else {
@@ -1047,7 +1066,7 @@ static void fill_geom(const sdr_handle* h, long long nout, long long in0, long l
     }
     g.tiles = (int)((nout + g.tile_out - 1) / g.tile_out);
     g.pipe_nch = g.pipe_tpw = 0;
-    if (!g.mfma && (h->pipe_mode >= 2 || (h->pipe_mode == 1 && h->in_fmt == SDR_IN_CU8))) {
+    if (!g.mfma && !g.win && (h->pipe_mode >= 2 || (h->pipe_mode == 1 && h->in_fmt == SDR_IN_CU8))) {
         // k_frontend_pipe: float tile only (cu8 needs no raw area), so the tile size is chosen
         // as for complex64 input; chunks per lane must fit one of the instantiations
         const int D = h->cfg.decim, nt = h->ntaps, spc = h->in_fmt == SDR_IN_CU8 ? 8 : 2;

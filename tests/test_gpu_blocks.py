@@ -111,6 +111,29 @@ def test_somfy_decode_kat(kat):
     assert (r["control"], r["rolling_code"], r["address"]) == (1, 5, 0x365240)
 
 
+def test_somfy_decode_reference_script_fixtures():
+    """blocks.somfy_decode (rule kernel on the on-air envelope) against what the reference's own
+    somfy/decoder.py printed for the same half-symbols (tests/golden/somfy_fixtures.json, made by executing the
+    script in the build container).  Arrays with (0,0)/(1,1) pairs are not Manchester and have no on-air
+    form: they are covered on the oracle side only (tests/test_oracle_kat.py)."""
+    from sdr_amd import blocks
+    from tests.test_oracle_kat import _somfy_fixture_cases
+    n = 0
+    for c in _somfy_fixture_cases():
+        if c["kind"] == "invalid_pair":
+            continue
+        r = blocks.somfy_decode(c["manchester"])
+        assert r["payload"].hex() == c["payload_hex"] and r["frame"].hex() == c["frame_hex"]
+        assert r["checksum_ok"] == c["checksum_ok"] and r["key"] == c["key"]
+        if c["exception"] is None:
+            assert (r["control"], r["rolling_code"], r["address"]) == (c["control"], c["rolling_code"], c["address"])
+        else:
+            assert r["control"] not in odec.SOMFY_COMMANDS
+        assert r == odec.somfy_decode(c["manchester"])
+        n += 1
+    assert n >= 40
+
+
 def _preamble_lines(prints):
     """oracle print records -> the text print() would have produced"""
     return [" ".join(str(v) for v in p) for p in prints]

@@ -1,0 +1,101 @@
+"""The sliding-window channel filter (k_frontend_win: decimation 1, real taps, 10 outputs per lane) must
+equal the oracle and the one-output-per-lane kernel word for word: same fmaf chain, oldest sample first.
+SDR_FRONTEND (read by sdr_create) forces a kernel."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import dsp as odsp
+from tests.test_gpu_mfma import _chain, _iq, _same_words
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("ntaps", [1, 2, 7, 15, 16, 17, 27, 31, 32, 33, 121, 333])
+def test_win_fir_complex_out_bit_exact(ntaps):
+    from sdr_amd import chain
+    rng = np.random.default_rng(ntaps * 17)
+    taps = rng.standard_normal(ntaps).astype(np.float32) / np.float32(max(1, ntaps) ** 0.5)
+    for n in (40000 + 777, 1234, 5):          # 256-thread tiles + ragged tail; 64-thread tiles; shorter than the taps
+        x = _iq(n, ntaps + n, ncap=3)
+        got = {}
+        for mode in ("win", "valu"):
+            c = _chain(mode, 1e6, decim=1, taps=taps, demod=chain.DEMOD_NONE, tap_demod=True, max_batch=3, max_samples=n)
+            c.batch_process(x)
+            got[mode] = c.fetch_demod().reshape(3, -1)
+            c.close()
+        assert _same_words(got["win"], got["valu"])
+        for i in range(3):
+            assert _same_words(got["win"][i], odsp.fir_ccf(x[i], taps, 1))
+
+
+@pytest.mark.parametrize("demod", ["mag2", "quad"])
+@pytest.mark.parametrize("keep_n", [1, 3, 100])
+@pytest.mark.parametrize("stride_extra", [0, 1])
+def test_win_demod_slicer_aligned_and_odd_strides(demod, keep_n, stride_extra):
+    """even stride: 16-B DMA staging, captures whose tiles start on odd samples take the shifted tap table;
+    odd stride: the guarded staging path.  Floats + sliced bytes vs the oracle chain."""
+    from sdr_amd import _lib, chain
+    taps = odsp.low_pass(1.0, 2e6, 500e3, 250e3, odsp.WIN_BLACKMAN) if demod == "quad" else odsp.low_pass(1.0, 2e6, 20e3, 40e3)
+    n = 30000 + 301
+    ncap = 3
+    st = n + 1 + stride_extra      # n is odd: stride_extra 0 -> even stride (aligned), 1 -> odd
+    flat = _iq(ncap * st, 11 + keep_n) * np.float32(0.5)
+    x = np.stack([flat[i * st:i * st + n] for i in range(ncap)])
+    gain = 3.0 if demod == "mag2" else 0.7
+    lo, hi = (0.05, 0.15) if demod == "mag2" else (-0.3, 0.3)
+    dm = chain.DEMOD_MAG2 if demod == "mag2" else chain.DEMOD_QUAD
+    res = {}
+    for mode in ("win", "valu"):
+        c = _chain(mode, 1e6, decim=1, taps=taps, demod=dm, demod_gain=gain, thr=(lo, hi), keep_n=keep_n,
+                   tap_demod=True, max_batch=ncap, max_samples=n)
+        _lib.check(c._h, c._L.sdr_batch_process(c._h, C.c_void_p(flat.ctypes.data), n, st, ncap, 0, C.byref(c.out)))
+        res[mode] = (c.fetch_demod().reshape(ncap, -1), c.fetch_bits().reshape(ncap, -1))
+        c.close()
+    assert _same_words(res["win"][0], res["valu"][0])
+    np.testing.assert_array_equal(res["win"][1], res["valu"][1])
+    for i in range(ncap):
+        y = odsp.fir_ccf(x[i], taps, 1)
+        v = odsp.mag2(y) if demod == "mag2" else odsp.quad_demod(y, 1.0)
+        assert _same_words(res["win"][0][i], np.float32(gain) * v)
+        b, _, _ = odsp.slice_bits(v, gain, lo, hi, keep_n)
+        np.testing.assert_array_equal(res["win"][1][i], b)
+
+
+def test_win_streaming_ragged_chunks_equal_one_shot():
+    from sdr_amd import chain
+    taps = odsp.low_pass(1.0, 2e6, 500e3, 250e3, odsp.WIN_BLACKMAN)     # 27 taps (TFA/decoder.grc)
+    n = 60000
+    x = _iq(n, 5) * np.float32(0.4)
+    want_v = odsp.quad_demod(odsp.fir_ccf(x, taps, 1), 1.0)
+    want_b, _, _ = odsp.slice_bits(want_v, 1.0, -0.2, 0.2, 3)
+    c = _chain("win", 1e6, decim=1, taps=taps, demod=chain.DEMOD_QUAD, thr=(-0.2, 0.2), keep_n=3, tap_demod=True,
+               max_samples=n)
+    cuts = [0, 1, 2, 5, 1500, 1501, 4096, 4099, 7000, 40001, n]
+    fl, bi = [], []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        c.process_iq(x[a:b])
+        fl.append(c.fetch_demod())
+        bi.append(c.fetch_bits())
+    c.close()
+    assert _same_words(np.concatenate(fl), want_v)
+    np.testing.assert_array_equal(np.concatenate(bi), want_b)
+
+
+def test_win_nonfinite_sample_stays_local():
+    """no 0*x products: an Inf sample spoils exactly the ntaps outputs whose window holds it (the shifted tap
+    table of odd tile starts skips its dummy step instead of multiplying by zero)"""
+    from sdr_amd import chain
+    taps = odsp.low_pass(1.0, 2e6, 500e3, 250e3, odsp.WIN_BLACKMAN)
+    n = 20000
+    for pos in (0, 5000, 5001, 2559, 2560, n - 1):
+        x = _iq(n, 9, ncap=2) * np.float32(0.3)
+        x[1, pos] = np.inf
+        c = _chain("win", 1e6, decim=1, taps=taps, demod=chain.DEMOD_NONE, tap_demod=True, max_batch=2, max_samples=n)
+        c.batch_process(x)
+        y = c.fetch_demod().reshape(2, -1)
+        c.close()
+        bad = ~np.isfinite(y[1])
+        assert bad.sum() == min(taps.size, n - pos) and bad[pos:pos + taps.size].all()
+        assert np.isfinite(y[0]).all()

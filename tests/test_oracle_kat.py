@@ -271,3 +271,30 @@ def test_velux_reference_arrays(kat):
     d2 = dec.velux_decode(kat["velux_commented"]["bits"])
     assert d2["crc_ok"] is False and d2["counter"] == kat["velux_commented"]["counter"]
     assert dec.velux_decode([0, 1] * 100) is None
+
+
+# ---- somfy/decoder.py run on substituted arrays (tests/golden/make_somfy_fixtures.py executed the reference
+# script itself in the build container): 56 cases pin row a11 beyond the single README frame
+def _somfy_fixture_cases():
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "somfy_fixtures.json")) as f:
+        return json.load(f)["cases"]
+
+
+def test_somfy_decode_matches_reference_script_outputs():
+    cases = _somfy_fixture_cases()
+    assert len(cases) >= 50
+    kinds = set()
+    for c in cases:
+        r = dec.somfy_decode(c["manchester"])
+        kinds.add(c["kind"])
+        assert r["payload"].hex() == c["payload_hex"]
+        assert r["frame"].hex() == c["frame_hex"]
+        assert r["checksum_ok"] == c["checksum_ok"] and r["key"] == c["key"]
+        if c["exception"] is None:
+            assert (r["control"], r["rolling_code"], r["address"]) == (c["control"], c["rolling_code"], c["address"])
+            assert dec.SOMFY_COMMANDS[r["control"]] == c["control_name"]
+        else:   # the script raises KeyError at its COMMANDS lookup: control is not a known command
+            assert c["exception"] == "KeyError" and r["control"] not in dec.SOMFY_COMMANDS
+    assert kinds == {"valid", "unknown_control", "bit_flip", "invalid_pair"}
