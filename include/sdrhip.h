@@ -195,7 +195,14 @@ SDR_API const char* sdr_last_error(sdr_handle* h);
  * ref: gr::block::general_work of the C++ blocks + blk.work(input_items,
  * output_items) of the epy decoder (TS33C/live_decoder.grc:665-845): FIR
  * history, NCO phase, hysteresis bit, keep_one_in_n counter and the decoder's
- * rawBuffer/currentSymbols state all persist between calls.
+ * rawBuffer/currentSymbols state all persist between calls.  The callback-rule
+ * decoders (SDR_DEC_SOMFY .. SDR_DEC_BALDR; ref: the pigpio callbacks of
+ * somfy/sniff.py:28-117, berner/sniff.py:21-44, mumbi/sniff.py:26-65) keep their
+ * state, collected bits, clock and tick of the last edge (absolute microseconds
+ * since stream start) too: a frame cut by a call boundary decodes as in one pass;
+ * a streaming call runs the rule edge by edge on one wavefront (the batch entry
+ * point keeps the 64-edges-at-a-time form).  SDR_DEC_VELUX alone treats every
+ * call as one capture (the reference script decodes one array).
  * iq: n complex64 samples (interleaved re,im), host or device pointer. */
 SDR_API int sdr_process_iq(sdr_handle* h, const void* iq, size_t n, int is_device_ptr, sdr_out* out);
 /* ref: StreamDecoder.work([chunk]) (TS33C/stream_decoder.py:39): decoder only,

@@ -300,11 +300,81 @@ struct EdgeCtx {
     int first_level;
     long long rate_hz;
     int wave;                // device: all 64 lanes of the wavefront run the rule (EdgeReader may broadcast)
+    long long base;          // streaming: decoder-rate samples consumed before this call (ticks are absolute)
+    RuleState* rs;           // streaming: the callback's state between calls (nullptr: one call = one capture)
 };
 SDR_HD inline long long tick_of(const EdgeCtx& e, long long k)
 {
     if (e.ticks) return e.ticks[k];
-    return ((long long)e.pos[k] * 1000000LL) / e.rate_hz;
+    return ((e.base + (long long)e.pos[k]) * 1000000LL) / e.rate_hz;
+}
+
+// What a pigpio callback object keeps between edges (somfy/sniff.py:19-26, berner/sniff.py:17-19,
+// mumbi/sniff.py:19-24, kwmobile/decoder.py:87-93, baldr/decoder.py:79-85), as local variables of one
+// rule run.  One call = one capture: they start fresh.  Streaming (e.rs): loaded from / stored to the
+// handle's RuleState, so the rule sees ONE continuous edge stream however the caller cuts it.
+struct RuleVars {
+    long long start_tick = 0, prev_tick = 0;
+    int state = 0, nbits = 0, level = 0, n_sync = 0, clock = 640;
+    double sync_sum = 0.0;
+};
+SDR_HD inline void rule_sync(const EdgeCtx& e)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (e.wave) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+#endif
+}
+SDR_HD inline void rule_load(const EdgeCtx& e, RuleVars& v, unsigned char* bits)
+{
+    if (!e.rs || !e.rs->valid) return;
+    v.start_tick = e.rs->start_tick;
+    v.prev_tick = e.rs->prev_tick;
+    v.state = e.rs->state;
+    v.nbits = e.rs->nbits;
+    v.level = e.rs->level;
+    v.n_sync = e.rs->n_sync;
+    v.clock = e.rs->clock;
+    v.sync_sum = e.rs->sync_sum;
+    if (bits) {
+        int i0 = 0, step = 1;
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (e.wave) {
+            i0 = (int)(threadIdx.x & 63);
+            step = 64;
+        }
+#endif
+        for (int i = i0; i < 512; i += step) bits[i] = e.rs->bits[i];
+        rule_sync(e);
+    }
+}
+SDR_HD inline void rule_store(const EdgeCtx& e, const RuleVars& v, int level, const unsigned char* bits)
+{
+    if (!e.rs) return;
+    rule_sync(e);
+    if (bits) {
+        int i0 = 0, step = 1;
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (e.wave) {
+            i0 = (int)(threadIdx.x & 63);
+            step = 64;
+        }
+#endif
+        const int n = v.nbits < 512 ? v.nbits : 512;
+        for (int i = i0; i < n; i += step) e.rs->bits[i] = bits[i];
+    }
+    e.rs->start_tick = v.start_tick;
+    e.rs->prev_tick = v.prev_tick;
+    e.rs->state = v.state;
+    e.rs->nbits = v.nbits;
+    e.rs->level = level;
+    e.rs->n_sync = v.n_sync;
+    e.rs->clock = v.clock;
+    e.rs->sync_sum = v.sync_sum;
+    e.rs->base = e.base + e.nb;
+    e.rs->valid = 1;
 }
 
 // Edge k's tick and position for the rule loops.  On the device, when the whole wavefront
@@ -505,17 +575,19 @@ SDR_HD inline void rule_somfy(const EdgeCtx& e, const BackParams& P, DecState* s
                                   unsigned char* bits /* >= 512 */)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    if (e.wave) {
+    if (e.wave && !e.rs) {
         wave_rule_somfy(e, P, st, cap, bits);
         return;
     }
 #endif
     const int tol = 100;
-    long long start_tick = 0;
-    int state = 0, nbits = 0, clock = 640, n_sync = 0;
-    double sync_sum = 0.0;  // np.average of <8 values: sequential sum
+    RuleVars rv;
+    rule_load(e, rv, bits);
+    long long& start_tick = rv.start_tick;
+    int &state = rv.state, &nbits = rv.nbits, &clock = rv.clock, &n_sync = rv.n_sync;
+    double& sync_sum = rv.sync_sum;  // np.average of <8 values: sequential sum
     const int wd = 20000;
-    long long prev_tick = 0;
+    long long& prev_tick = rv.prev_tick;
     auto watchdog = [&](long long at_run) {
         if (state > 0) {
             // bits = bits[1:]; pad one zero if short
@@ -578,10 +650,9 @@ SDR_HD inline void rule_somfy(const EdgeCtx& e, const BackParams& P, DecState* s
                 push(1, 1);
         }
     };
-    int level = e.first_level;
-    if (level == 1) event(1, 0);
+    int level = rv.level;   // level before the row's first byte (0 at stream start)
     EdgeReader rd(e);
-    for (long long k = 1; k < e.R; ++k) {
+    for (long long k = (e.first_level != level) ? 0 : 1; k < e.R; ++k) {
         long long tick, at;
         rd.get(k, tick, at);
         if (sat_delta(tick - prev_tick) > wd) watchdog(at);
@@ -589,8 +660,9 @@ SDR_HD inline void rule_somfy(const EdgeCtx& e, const BackParams& P, DecState* s
         event(level, tick);
         prev_tick = tick;
     }
-    long long end_tick = (e.nb * 1000000LL) / e.rate_hz;
+    long long end_tick = ((e.base + e.nb) * 1000000LL) / e.rate_hz;
     if (sat_delta(end_tick - prev_tick) > wd) watchdog(e.nb);
+    rule_store(e, rv, level, bits);
 }
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -657,14 +729,15 @@ SDR_HD inline void rule_berner(const EdgeCtx& e, const BackParams& P, DecState* 
                                    unsigned char* bits)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    if (e.wave) {
+    if (e.wave && !e.rs) {
         wave_rule_berner(e, P, st, cap);
         return;
     }
 #endif
-    long long start_tick = 0;
-    int state = 0, nbits = 0;
-    int level = e.first_level;
+    RuleVars rv;
+    rule_load(e, rv, bits);
+    long long& start_tick = rv.start_tick;
+    int &state = rv.state, &nbits = rv.nbits;
     auto event = [&](int lvl, long long tick, long long at) {
         if (lvl == 1)
             start_tick = tick;
@@ -693,14 +766,15 @@ SDR_HD inline void rule_berner(const EdgeCtx& e, const BackParams& P, DecState* 
             }
         }
     };
-    if (level == 1) event(1, 0, 0);
+    int level = rv.level;   // level before the row's first byte (0 at stream start)
     EdgeReader rd(e);
-    for (long long k = 1; k < e.R; ++k) {
+    for (long long k = (e.first_level != level) ? 0 : 1; k < e.R; ++k) {
         level ^= 1;
         long long tick, at;
         rd.get(k, tick, at);
         event(level, tick, at);
     }
+    rule_store(e, rv, level, bits);
 }
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -777,16 +851,17 @@ SDR_HD inline void rule_mumbi(const EdgeCtx& e, const BackParams& P, DecState* s
                                   unsigned char* bits)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    if (e.wave) {
+    if (e.wave && !e.rs) {
         wave_rule_mumbi(e, P, st, cap);
         return;
     }
 #endif
     const int tol = 50;
     const int wd = 8000;
-    long long start_tick = 0, prev_tick = 0;
-    int state = 0, nbits = 0;
-    int level = e.first_level;
+    RuleVars rv;
+    rule_load(e, rv, bits);
+    long long &start_tick = rv.start_tick, &prev_tick = rv.prev_tick;
+    int &state = rv.state, &nbits = rv.nbits;
     auto watchdog = [&](long long at) {
         if (state > 0) {
             if (nbits == 34) {
@@ -817,9 +892,9 @@ SDR_HD inline void rule_mumbi(const EdgeCtx& e, const BackParams& P, DecState* s
             }
         }
     };
-    if (level == 1) event(1, 0);
+    int level = rv.level;   // level before the row's first byte (0 at stream start)
     EdgeReader rd(e);
-    for (long long k = 1; k < e.R; ++k) {
+    for (long long k = (e.first_level != level) ? 0 : 1; k < e.R; ++k) {
         long long tick, at;
         rd.get(k, tick, at);
         if (sat_delta(tick - prev_tick) > wd) watchdog(at);
@@ -827,8 +902,9 @@ SDR_HD inline void rule_mumbi(const EdgeCtx& e, const BackParams& P, DecState* s
         event(level, tick);
         prev_tick = tick;
     }
-    long long end_tick = (e.nb * 1000000LL) / e.rate_hz;
+    long long end_tick = ((e.base + e.nb) * 1000000LL) / e.rate_hz;
     if (sat_delta(end_tick - prev_tick) > wd) watchdog(e.nb);
+    rule_store(e, rv, level, bits);
 }
 
 // kwmobile/decoder.py:112-131 fields of the 36-bit frame (5 packed bytes)
@@ -966,16 +1042,17 @@ SDR_HD inline void rule_kwmobile(const EdgeCtx& e, const BackParams& P, DecState
                                  unsigned char* bits)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    if (e.wave) {
+    if (e.wave && !e.rs) {
         wave_rule_ppm<false>(e, P, st, cap);
         return;
     }
 #endif
     const int tol = 50;
     const int wd = 3000;
-    long long start_tick = 0, prev_tick = 0;
-    int state = 0, nbits = 0;
-    int level = e.first_level;
+    RuleVars rv;
+    rule_load(e, rv, bits);
+    long long &start_tick = rv.start_tick, &prev_tick = rv.prev_tick;
+    int &state = rv.state, &nbits = rv.nbits;
     auto watchdog = [&](long long at) {
         if (state > 0) {
             if (nbits == 36) {
@@ -1002,9 +1079,9 @@ SDR_HD inline void rule_kwmobile(const EdgeCtx& e, const BackParams& P, DecState
             if (nbits < 512) bits[nbits++] = 0;
         }
     };
-    if (level == 1) event(1, 0);
+    int level = rv.level;   // level before the row's first byte (0 at stream start)
     EdgeReader rd(e);
-    for (long long k = 1; k < e.R; ++k) {
+    for (long long k = (e.first_level != level) ? 0 : 1; k < e.R; ++k) {
         long long tick, at;
         rd.get(k, tick, at);
         if (sat_delta(tick - prev_tick) > wd) watchdog(at);
@@ -1012,8 +1089,9 @@ SDR_HD inline void rule_kwmobile(const EdgeCtx& e, const BackParams& P, DecState
         event(level, tick);
         prev_tick = tick;
     }
-    long long end_tick = (e.nb * 1000000LL) / e.rate_hz;
+    long long end_tick = ((e.base + e.nb) * 1000000LL) / e.rate_hz;
     if (sat_delta(end_tick - prev_tick) > wd) watchdog(e.nb);
+    rule_store(e, rv, level, bits);
 }
 
 // baldr/decoder.py:87-142 (watchdog 18 ms, :152): one decode per transmission, of the
@@ -1022,7 +1100,7 @@ SDR_HD inline void rule_baldr(const EdgeCtx& e, const BackParams& P, DecState* s
                               unsigned char* bits)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    if (e.wave) {
+    if (e.wave && !e.rs) {
         wave_rule_ppm<true>(e, P, st, cap);
         return;
     }
@@ -1030,9 +1108,10 @@ SDR_HD inline void rule_baldr(const EdgeCtx& e, const BackParams& P, DecState* s
     const int tol = 200;
     const int wd = 18000;
     const int medium = 2650, lng = 4700, verylong = 9600;
-    long long start_tick = 0, prev_tick = 0;
-    int state = 0, nbits = 0;
-    int level = e.first_level;
+    RuleVars rv;
+    rule_load(e, rv, bits);
+    long long &start_tick = rv.start_tick, &prev_tick = rv.prev_tick;
+    int &state = rv.state, &nbits = rv.nbits;
     auto watchdog = [&](long long at) {
         if (state > 0) {
             if (nbits == 37) {
@@ -1066,9 +1145,9 @@ SDR_HD inline void rule_baldr(const EdgeCtx& e, const BackParams& P, DecState* s
             }
         }
     };
-    if (level == 1) event(1, 0);
+    int level = rv.level;   // level before the row's first byte (0 at stream start)
     EdgeReader rd(e);
-    for (long long k = 1; k < e.R; ++k) {
+    for (long long k = (e.first_level != level) ? 0 : 1; k < e.R; ++k) {
         long long tick, at;
         rd.get(k, tick, at);
         if (sat_delta(tick - prev_tick) > wd) watchdog(at);
@@ -1076,8 +1155,9 @@ SDR_HD inline void rule_baldr(const EdgeCtx& e, const BackParams& P, DecState* s
         event(level, tick);
         prev_tick = tick;
     }
-    long long end_tick = (e.nb * 1000000LL) / e.rate_hz;
+    long long end_tick = ((e.base + e.nb) * 1000000LL) / e.rate_hz;
     if (sat_delta(end_tick - prev_tick) > wd) watchdog(e.nb);
+    rule_store(e, rv, level, bits);
 }
 
 // velux/decoder.py:30-101 (io-homecontrol): the sliced stream is one byte per symbol.

@@ -379,12 +379,15 @@ __global__ void __launch_bounds__(BK_THREADS, 6) k_backend(BackParams P)
     // run widths (stream decoders) or edge ticks (callback rules) into LDS
     const bool stream_dec = P.decoder <= SDR_DEC_TFA_GRC;
     const int32_t* rpos = pos_in_lds ? s_pos : pos;
+    // streaming rule decoders: ticks are absolute, the callback's state comes from / goes to P.rule
+    RuleState* const rs = (!stream_dec && P.decoder != SDR_DEC_VELUX && cap == 0) ? P.rule : nullptr;
+    const long long rule_base = (rs && rs->valid) ? rs->base : 0;
     if (w_in_lds) {
         if (stream_dec)
             for (long long k = tid; k < R; k += BK_THREADS) s_w[k] = run_width(rpos, k, P.dec_rate);
         else
             for (long long k = tid; k < R; k += BK_THREADS)
-                s_tick[k] = ((long long)rpos[k] * 1000000LL) / (long long)P.dec_rate;
+                s_tick[k] = ((rule_base + (long long)rpos[k]) * 1000000LL) / (long long)P.dec_rate;
     }
     double* gcur = P.cur + (long long)cap * SDR_CUR_CAP;
     if (stream_dec) {
@@ -413,7 +416,7 @@ __global__ void __launch_bounds__(BK_THREADS, 6) k_backend(BackParams P)
         // all 64 lanes of wavefront 0 run the rule on identical (wave-uniform) values: control flow is
         // scalar branches instead of exec masking, every LDS read is a broadcast; the redundant stores
         // hit the same addresses with the same data
-        EdgeCtx e{pos_in_lds ? s_pos : pos, w_in_lds ? s_tick : nullptr, R, nb, first_level, (long long)P.dec_rate, 1};
+        EdgeCtx e{pos_in_lds ? s_pos : pos, w_in_lds ? s_tick : nullptr, R, nb, first_level, (long long)P.dec_rate, 1, rule_base, rs};
         if (P.decoder == SDR_DEC_SOMFY)
             rule_somfy(e, P, &ls, cap, s_bits);
         else if (P.decoder == SDR_DEC_BERNER)

@@ -29,6 +29,19 @@ struct DecState {
     double gap_short_limit;
 };
 
+// pigpio-callback rule decoders (somfy / berner / mumbi / kwmobile / baldr): what the callback object
+// keeps between edges, carried between STREAMING calls (ref: somfy/sniff.py:19-26 start_tick, state, bits,
+// hw_sync, clock).  Ticks are absolute microseconds since stream start.
+struct RuleState {
+    long long base;          // decoder-rate samples consumed by the calls so far
+    long long start_tick, prev_tick;
+    int32_t valid;           // 0: stream start (all defaults)
+    int32_t state, nbits, level, n_sync, clock;
+    int32_t pad_;
+    double sync_sum;
+    unsigned char bits[512];
+};
+
 struct FrontParams {
     const float2* x;        // capture 0, sample 0
     const float2* hist;     // streaming: hist_len samples that precede x[0]; nullptr = zeros
@@ -168,4 +181,5 @@ struct BackParams {
     // k_decode_pieces, one wavefront each
     int32_t* pieces_b;      // per capture (bits_stride ints, the runs_seg slice): run index behind every over-limit width
     int32_t* pieces_hdr;    // per capture 8 ints: [0] 1 = delegated, [1] over-limit widths, [2] frames of the first piece, [3] frames of the middle pieces
+    RuleState* rule;        // streaming call with a callback-rule decoder: its state between calls (row 0); nullptr = one call per capture
 };

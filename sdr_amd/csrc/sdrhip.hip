@@ -71,6 +71,7 @@ struct sdr_handle {
     long long runs_cap = 0;
     double* d_cur = nullptr;
     DecState* d_st = nullptr;
+    RuleState* d_rule = nullptr;    // callback-rule decoders: state between streaming calls
     sdr_frame* d_frames = nullptr;
 
     // streaming state tracked on the host (pure functions of the sample counts)
@@ -445,6 +446,7 @@ static int reset_dec_state(sdr_handle* h)
     s0.pulse_short_limit = 775.0;
     s0.gap_short_limit = 775.0;
     HIPCHK(h, hipMemcpy(h->d_st, &s0, sizeof s0, hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemset(h->d_rule, 0, sizeof(RuleState)));
     h->carry_next = h->cfg.thr_init;
     h->carry_last = -1;
     return SDR_OK;
@@ -464,7 +466,7 @@ extern "C" int sdr_destroy(sdr_handle* h)
     if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
     void* ptrs[] = {h->d_rtaps, h->d_post_rtaps, h->d_nco_tab, h->d_atan_tab, h->d_pow, h->d_log2, h->d_iq,
                     h->d_hist[0], h->d_hist[1], h->d_bits, h->d_tap, h->d_tap2, h->d_tsum, h->d_runs, h->d_runs_seg, h->d_seg_cnt, h->d_runs_n, h->d_pieces_hdr,
-                    h->d_cur, h->d_st, h->d_frames, h->d_sq_y, h->d_sq_z, h->d_sq_cnt, h->d_sq_st,
+                    h->d_cur, h->d_st, h->d_rule, h->d_frames, h->d_sq_y, h->d_sq_z, h->d_sq_cnt, h->d_sq_st,
                     h->d_post_hist[0], h->d_post_hist[1], h->d_pack, h->d_pfb_taps, h->d_pfb_tw};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -567,6 +569,7 @@ extern "C" int sdr_create(const sdr_chain_cfg* cfg, sdr_handle** out)
         HIPCHK(h, dev_alloc((void**)&h->d_cur, (size_t)(B * SDR_CUR_CAP) * sizeof(double)));
         HIPCHK(h, dev_alloc((void**)&h->d_st, (size_t)B * sizeof(DecState)));
         HIPCHK(h, hipMemset(h->d_st, 0, (size_t)B * sizeof(DecState)));
+        HIPCHK(h, dev_alloc((void**)&h->d_rule, sizeof(RuleState)));
         {
             int r2 = reset_dec_state(h);
             if (r2) return r2;
@@ -1003,6 +1006,7 @@ static int launch_back(sdr_handle* h, int ncap, const CallGeom& g, long long pat
     Bp.pow_m13 = h->d_pow;
     Bp.log2n = h->d_log2;
     Bp.runs_n = h->d_runs_n;
+    Bp.rule = (!fresh && ncap == 1 && !is_stream_decoder(c.decoder) && c.decoder != SDR_DEC_NONE) ? h->d_rule : nullptr;
     const bool full_pass = run_decoder && c.decoder != SDR_DEC_NONE && !Bp.nout_var;
     if (h->reuse_next && h->runs_valid && full_pass && !h->no_reuse) {
         Bp.reuse_runs = 1;

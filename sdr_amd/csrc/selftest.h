@@ -11,6 +11,7 @@ struct SelftestDec {
     int decoder;
     double rate;
     DecState st;
+    RuleState rs;
     std::vector<double> cur, cur_l, scratch, pw, lg;
     std::vector<int8_t> raw;
     std::vector<sdr_frame> frames;
@@ -39,6 +40,7 @@ extern "C" SDR_API void* sdr_selftest_dec_create(int decoder, double rate)
     d->decoder = decoder;
     d->rate = rate;
     memset(&d->st, 0, sizeof d->st);
+    memset(&d->rs, 0, sizeof d->rs);
     d->st.pulse_short_limit = d->st.gap_short_limit = 775.0;
     d->cur.assign(SDR_CUR_CAP, 0.0);
     d->cur_l.assign(SDR_CUR_CAP, 0.0);
@@ -87,7 +89,9 @@ extern "C" SDR_API int sdr_selftest_dec_work(void* p, const int8_t* bits, size_t
                           d->cur.data(), &d->st, d->scratch.data());
         else {
             std::vector<unsigned char> sb(512);
-            EdgeCtx e{pos.data(), nullptr, R, nb, first_level, (long long)d->rate, 0};
+            // consecutive calls are one continuous edge stream for the callback rules (velux: one call = one capture)
+            RuleState* rs = d->decoder == SDR_DEC_VELUX ? nullptr : &d->rs;
+            EdgeCtx e{pos.data(), nullptr, R, nb, first_level, (long long)d->rate, 0, (rs && rs->valid) ? rs->base : 0, rs};
             if (d->decoder == SDR_DEC_SOMFY) rule_somfy(e, P, &d->st, 0, sb.data());
             if (d->decoder == SDR_DEC_BERNER) rule_berner(e, P, &d->st, 0, sb.data());
             if (d->decoder == SDR_DEC_MUMBI) rule_mumbi(e, P, &d->st, 0, sb.data());

@@ -346,3 +346,90 @@ def test_velux_host_vs_oracle(L, kat):
                 if o["error"] is None:
                     assert f.temp_tenths == o["counter"] and int(f.lim[1]) == o["message_length"]
         g.close()
+
+
+def _rule_stream(rng, kind, rate):
+    """several transmissions of one emitter with idle gaps and junk between them"""
+    sym = []
+    for _ in range(int(rng.integers(2, 4))):
+        if kind == "somfy":
+            fr = synth.somfy_frame(0xA0 | int(rng.integers(0, 16)), int(rng.choice([1, 2, 4, 8])), int(rng.integers(0, 65536)),
+                                   int(rng.integers(0, 1 << 24)))
+            sym += synth.somfy_symbols(fr, repeats=int(rng.integers(0, 3)), wakeup=bool(rng.integers(0, 2)))
+        elif kind == "berner":
+            sym += synth.berner_symbols(int(rng.integers(0, 1 << 32)), repeats=int(rng.integers(1, 5)))
+        elif kind == "mumbi":
+            codes = sorted(synth.MUMBI_CODES)
+            sym += synth.mumbi_symbols(bytes(bytearray(synth.MUMBI_CODES[codes[int(rng.integers(0, len(codes)))]])),
+                                       repeats=int(rng.integers(1, 5)), on_air=bool(rng.integers(0, 2)))
+        elif kind == "kwmobile":
+            sym += synth.kwmobile_symbols(synth.kwmobile_bits(int(rng.integers(0, 256)), int(rng.integers(0, 3)), True,
+                                                              int(rng.integers(-300, 500)), int(rng.integers(0, 100))),
+                                          repeats=int(rng.integers(2, 6)))
+        else:
+            sym += synth.baldr_symbols(synth.baldr_bits(int(rng.integers(0, 256)), int(rng.integers(0, 3)), int(rng.integers(0, 2)),
+                                                        int(rng.integers(-300, 500)), int(rng.integers(0, 100))),
+                                       repeats=int(rng.integers(1, 4)))
+        r = rng.random()
+        if r < 0.4:
+            for _ in range(int(rng.integers(1, 20))):
+                sym += [(1, float(rng.integers(30, 1200))), (0, float(rng.integers(30, 1200)))]
+        sym += [(0, float(rng.integers(500, 45000)))]
+    env = synth.envelope(sym, rate, lead_in_us=float(rng.integers(0, 9000))).astype(np.int8)
+    env = np.concatenate([env, np.zeros(int(rng.integers(0, 30000)), np.int8)])
+    if rng.random() < 0.25:
+        env = (1 - env).astype(np.int8)
+    return env
+
+
+RULE_SET = [("somfy", _lib.DEC_SOMFY, dec.SomfySniffer, 20000), ("berner", _lib.DEC_BERNER, dec.BernerSniffer, None),
+            ("mumbi", _lib.DEC_MUMBI, dec.MumbiSniffer, 8000), ("kwmobile", _lib.DEC_KWMOBILE, dec.KwmobileDecoder, 3000),
+            ("baldr", _lib.DEC_BALDR, dec.BaldrDecoder, 18000)]
+
+
+def rule_frame_key(decoder, f):
+    """comparable form of a device/host frame record"""
+    if decoder == _lib.DEC_SOMFY:
+        return (bytes(bytearray(f.raw[:7])), f.packet(), f.status == 0, f.v[3])
+    return f.packet()
+
+
+def oracle_frame_key(decoder, a):
+    if decoder == _lib.DEC_SOMFY:
+        return (a["raw"], a["frame"], a["checksum_ok"], a["clock"])
+    if decoder in (_lib.DEC_KWMOBILE, _lib.DEC_BALDR):
+        return a["frame"]
+    return a
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_rule_decoders_carry_state_across_calls(L, seed):
+    """The pigpio callbacks are continuous (somfy/sniff.py:28-117, berner/sniff.py:21-44, mumbi/sniff.py:26-65,
+    kwmobile/decoder.py:95-135, baldr/decoder.py:87-142): a frame cut by a call boundary must still decode.
+    Every emitter stream runs through EVERY rule in ragged chunks (cuts inside pulses, inside frames, empty
+    chunks, one-byte chunks); the frames of all calls together equal the oracle sniffer fed the whole stream."""
+    rng = np.random.default_rng(900 + seed)
+    total = 0
+    for kind, _, _, _ in RULE_SET:
+        rate = int(rng.choice([100000, 250000, 1000000]))
+        env = _rule_stream(rng, kind, rate)
+        for _, decoder, cls, wd in RULE_SET:
+            want = [oracle_frame_key(decoder, a) for a in _events_decode(cls, env, rate, wd)]
+            for mode in ("ragged", "tiny", "one"):
+                if mode == "one":
+                    cuts = [0, env.size]
+                elif mode == "tiny":
+                    cuts = sorted(set([0, env.size] + [int(v) for v in rng.integers(0, env.size, 60)]))
+                else:
+                    cuts = sorted(set([0, env.size] + [int(v) for v in rng.integers(0, env.size, 7)]))
+                    cuts = cuts[:3] + [cuts[2]] + cuts[3:]          # an empty call
+                    if env.size > 10:
+                        cuts = sorted(cuts + [cuts[1] + 1])          # a one-byte call
+                g = HostDec(L, decoder, rate)
+                for a, b in zip(cuts[:-1], cuts[1:]):
+                    g.work(np.ascontiguousarray(env[a:b]))
+                got = [rule_frame_key(decoder, f) for f in g.frames]   # HostDec keeps the frames of all calls
+                g.close()
+                assert got == want, (kind, decoder, mode, rate)
+            total += len(want)
+    assert total >= 5

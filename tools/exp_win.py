@@ -3,6 +3,8 @@ usage: exp_win.py ntaps demod(mag2|quad) keep_n ncap log2n"""
 import os, sys, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sdr_amd import chain
+if len(sys.argv) < 6:
+    sys.argv = [sys.argv[0]] + os.environ.get("WIN_ARGS", "27 quad 1 64 20 win").split()
 nt, demod, keep, ncap, lg = int(sys.argv[1]), sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
 n = 1 << lg
 dev = torch.device("cuda", 0)

@@ -64,6 +64,15 @@ def one(rng, k):
             else:
                 c.redecode(dec)
             frames = c.fetch_frames()
+            # the same stream in ragged calls on a streaming handle (state carried between calls)
+            cuts = sorted(set([0, env.size] + [int(v) for v in rng.integers(0, env.size, int(rng.integers(1, 12)))]))
+            with chain.Chain(rate, decoder=dec, decoder_rate=rate, max_samples=env.size, max_frames=64) as cs:
+                chunked = []
+                for a0, b0 in zip(cuts[:-1], cuts[1:]):
+                    cs.process_bits(env[a0:b0])
+                    chunked += [(f.packet(), bytes(bytearray(f.raw[:7])), f.status, f.nbits) for f in cs.fetch_frames()]
+            if chunked != [(f.packet(), bytes(bytearray(f.raw[:7])), f.status, f.nbits) for f in frames]:
+                return desc + " decoder %d: %d-call streaming pass differs from the one-call pass (cuts %s)" % (dec, len(cuts) - 1, cuts)
             s = cls()
             for lvl, tick in odec.edges_to_events(env, rate, watchdog_us=wd):
                 s.cbf(lvl, tick)
