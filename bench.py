@@ -65,32 +65,112 @@ def make_batch(torch, dev, ncap, seed, FS=FS, N_PER_CAPTURE=N_PER_CAPTURE, F_OFF
     return iq, pkts
 
 
-def cpu_baseline(iq_gpu, taps, budget_s=12.0):
-    """The oracle (C restatement of the GNU Radio blocks + numpy restatement of
-    TS33C/stream_decoder.py) on one host core over a bounded sample of the same
-    captures.  A stand-in for the reference flowgraph (GNU Radio is not
-    installable here), reported beside the GPU number."""
+def timed_repeat(fn, min_s=1.0):
+    """Run fn() until at least min_s seconds of it have been timed -> (first result, repetitions, seconds)."""
+    first, reps, used = None, 0, 0.0
+    while used < min_s:
+        t0 = time.perf_counter()
+        r = fn()
+        used += time.perf_counter() - t0
+        if reps == 0:
+            first = r
+        reps += 1
+    return first, reps, used
+
+
+def host_cores():
+    """CPU threads this job may use: the affinity mask, capped by the box's per-GPU share (OMP_NUM_THREADS is
+    set to it there; os.cpu_count() shows the whole machine)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    cap = os.environ.get("OMP_NUM_THREADS")
+    if cap and cap.isdigit() and int(cap) > 0:
+        n = min(n, int(cap))
+    return max(1, n)
+
+
+def cpu_worker(path, first, count, budget_s):
+    """One host core of the all-cores CPU baseline (started by cpu_baseline as `bench.py --cpu-worker ...`, a
+    fresh process that never touches the GPU): the oracle chain + numpy TS33C decoder over its share of the
+    sampled captures, round and round until the budget is used.  Prints {"done", "seconds", "frames"}."""
     from oracle import decoders as odec
     from oracle import dsp as odsp
-    done = 0
-    t_used = 0.0
-    frames = 0
-    ncap = iq_gpu.shape[0]
-    i = 0
-    while t_used < budget_s:
-        x = iq_gpu[i % ncap].cpu().numpy().view(np.complex64).reshape(-1)
+    caps = np.load(path, mmap_mode="r")
+    taps = np.load(path + ".taps.npy")
+    done, used, frames, i = 0, 0.0, 0, 0
+    while used < budget_s:
+        x = np.ascontiguousarray(caps[first + i % count]).view(np.complex64).reshape(-1)
         t0 = time.perf_counter()
         bits = odsp.ook_chain(x, taps, DECIM, 1.0, 0.05, 0.15, 1, fc=F_OFF, fs=FS)
         d = odec.TS33CStreamDecoder(sample_rate=20000)
         d.work([bits])
-        t_used += time.perf_counter() - t0
+        used += time.perf_counter() - t0
         frames += len(d.frames)
         done += 1
         i += 1
+    print(json.dumps({"done": done, "seconds": used, "frames": frames}))
+
+
+def cpu_baseline(iq_gpu, taps, budget_s=10.0):
+    """The oracle (C restatement of the GNU Radio blocks + numpy restatement of TS33C/stream_decoder.py) over a
+    bounded sample of the same captures: one host core (the scalar port, `value`) and ALL the job's host
+    cores (one worker process per core over disjoint captures, `all_cores`).  A stand-in for the reference
+    flowgraph (GNU Radio is not installable here), reported beside the GPU number."""
+    import subprocess
+    import tempfile
+    from oracle import decoders as odec
+    from oracle import dsp as odsp
+    ncap = iq_gpu.shape[0]
+    cores = host_cores()
+    nsample = min(ncap, 2 * cores)
+    sample = iq_gpu[:nsample].cpu().numpy()
+
+    def one_pass(k=[0]):
+        x = sample[k[0] % nsample].view(np.complex64).reshape(-1)
+        k[0] += 1
+        bits = odsp.ook_chain(x, taps, DECIM, 1.0, 0.05, 0.15, 1, fc=F_OFF, fs=FS)
+        d = odec.TS33CStreamDecoder(sample_rate=20000)
+        d.work([bits])
+        return len(d.frames)
+
+    _, done, t_used = timed_repeat(one_pass, budget_s)
     msps = done * N_PER_CAPTURE / t_used / 1e6
-    return {"value": round(msps, 2), "unit": "Msps", "cores": 1, "kind": "port",
-            "sample": "%d capture passes x 2^18 samples drawn from the same batch, oracle C chain + numpy TS33C decoder, %.1f s"
-                      % (done, t_used)}
+    out = {"value": round(msps, 2), "unit": "Msps", "cores": 1, "kind": "port",
+           "sample": "%d capture passes x 2^18 samples drawn from the same batch, oracle C chain + numpy TS33C decoder, %.1f s"
+                     % (done, t_used)}
+    # all cores: one fresh worker process per core (no GPU in them), disjoint captures, same time budget
+    tmp = tempfile.mkdtemp(prefix="sdr_cpu_")
+    path = os.path.join(tmp, "caps.npy")
+    try:
+        np.save(path, sample)
+        np.save(path + ".taps.npy", np.asarray(taps, np.float32))
+        per = max(1, nsample // cores)
+        env = dict(os.environ)
+        env["OMP_NUM_THREADS"] = "1"
+        t0 = time.perf_counter()
+        procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", path, str((w * per) % nsample),
+                                   str(per), str(budget_s)], stdout=subprocess.PIPE, env=env) for w in range(cores)]
+        res = []
+        for p in procs:
+            o, _ = p.communicate()
+            if p.returncode != 0:
+                raise SystemExit("cpu_baseline: a worker failed (exit %d)" % p.returncode)
+            res.append(json.loads(o.decode().strip().splitlines()[-1]))
+        wall = time.perf_counter() - t0
+        total = sum(r["done"] for r in res)
+        rate = sum(r["done"] * N_PER_CAPTURE / r["seconds"] for r in res) / 1e6
+        out["all_cores"] = {"value": round(rate, 2), "unit": "Msps", "cores": cores, "kind": "port",
+                            "os_cpu_count": os.cpu_count(),
+                            "sample": "%d worker processes (one per core of this job's CPU share), %d capture passes in all, "
+                                      "%.1f s of oracle time each, %.1f s wall including start-up" % (cores, total, budget_s, wall)}
+    finally:
+        for f in (path, path + ".taps.npy"):
+            if os.path.exists(f):
+                os.remove(f)
+        os.rmdir(tmp)
+    return out
 
 
 def fm_workload(torch, dev, skip_cpu, n=1 << 24, fs=2.4e6, steps=20):
@@ -115,11 +195,9 @@ def fm_workload(torch, dev, skip_cpu, n=1 << 24, fs=2.4e6, steps=20):
     if not skip_cpu:
         from oracle import dsp as odsp
         m = 1 << 22
-        t0 = time.perf_counter()
-        want = odsp.fm_radio_chain(iq[:m], samp_rate=fs, shift=200e3)
-        tc = time.perf_counter() - t0
-        out["cpu_baseline"] = {"value": round(m / tc / 1e6, 2), "unit": "Msps", "cores": 1, "kind": "port",
-                               "sample": "first 2^22 samples, oracle C blocks, %.1f s" % tc}
+        want, reps, tc = timed_repeat(lambda: odsp.fm_radio_chain(iq[:m], samp_rate=fs, shift=200e3), 2.0)
+        out["cpu_baseline"] = {"value": round(reps * m / tc / 1e6, 2), "unit": "Msps", "cores": 1, "kind": "port",
+                               "sample": "first 2^22 samples x %d passes, oracle C blocks, %.1f s" % (reps, tc)}
         r.process(iq[:m])
         got = r.fetch(4)
         err = float(np.max(np.abs(got - want[4]))) / float(np.max(np.abs(want[4])))
@@ -178,15 +256,16 @@ def r_shape_workload(torch, dev, skip_cpu, ncap=64, n=1 << 19, fs=2e6, steps=20)
         from oracle import dsp as odsp
         bits = c.fetch_bits().reshape(ncap, -1)
         x = iq[0].cpu().numpy().view(np.complex64).reshape(-1)
-        t0 = time.perf_counter()
-        want = odsp.ook_chain(x, taps, 1, 1.0, 0.05, 0.15, 100)
-        d = odec.TS33CStreamDecoder(sample_rate=20000)
-        d.work([want])
-        tc = time.perf_counter() - t0
+        def cpu_pass():
+            w = odsp.ook_chain(x, taps, 1, 1.0, 0.05, 0.15, 100)
+            dd = odec.TS33CStreamDecoder(sample_rate=20000)
+            dd.work([w])
+            return w, dd
+        (want, d), reps, tc = timed_repeat(cpu_pass, 2.0)
         if not np.array_equal(bits[0], want) or [f["packet"] for f in d.frames] != got.get(0):
             raise SystemExit("R shape: capture 0 differs from the oracle")
-        out["cpu_baseline"] = {"value": round(n / tc / 1e6, 2), "unit": "Msps", "cores": 1, "kind": "port",
-                               "sample": "capture 0 (2^19 samples), oracle C chain + numpy TS33C decoder, %.2f s" % tc}
+        out["cpu_baseline"] = {"value": round(reps * n / tc / 1e6, 2), "unit": "Msps", "cores": 1, "kind": "port",
+                               "sample": "capture 0 (2^19 samples) x %d passes, oracle C chain + numpy TS33C decoder, %.2f s" % (reps, tc)}
         out["verified"] += "; capture 0 bit-exact vs oracle"
     c.close()
     return out
@@ -302,31 +381,29 @@ def tfa_fsk_workload(torch, dev, skip_cpu, ncap=64, n=1 << 20, fs=2e6, dev_hz=60
         from oracle import dsp as odsp
         bits = c.fetch_bits().reshape(ncap, -1)
         x = iq[0].cpu().numpy().view(np.complex64).reshape(-1)
-        t0 = time.perf_counter()
-        want = odsp.quad_demod(odsp.fir_ccf(x, taps, 1), gain)
-        wb, _, _ = odsp.slice_bits(want, 1.0, -0.2, 0.2, 1)
-        o = odec.TFAStreamDecoder(sample_rate=int(fs), nan_guard=True)
-        o.work([wb])
-        tc = time.perf_counter() - t0
+        def cpu_pass():
+            w = odsp.quad_demod(odsp.fir_ccf(x, taps, 1), gain)
+            b, _, _ = odsp.slice_bits(w, 1.0, -0.2, 0.2, 1)
+            oo = odec.TFAStreamDecoder(sample_rate=int(fs), nan_guard=True)
+            oo.work([b])
+            return b, oo
+        (wb, o), reps, tc = timed_repeat(cpu_pass, 2.0)
         mine = [f for f in frames if f.capture == 0]
         if not np.array_equal(bits[0], wb) or len(mine) != len(o.frames) or \
                 [f["packet"] for f in o.frames if f["status"] == "ok"] != [f.packet() for f in mine if f.status == 0]:
             raise SystemExit("TFA FSK: capture 0 differs from the oracle")
-        out["cpu_baseline"] = {"value": round(n / tc / 1e6, 2), "unit": "Msps", "cores": 1, "kind": "port",
-                               "sample": "capture 0 (2^20 samples), oracle C blocks + numpy TFA decoder, %.2f s" % tc}
+        out["cpu_baseline"] = {"value": round(reps * n / tc / 1e6, 2), "unit": "Msps", "cores": 1, "kind": "port",
+                               "sample": "capture 0 (2^20 samples) x %d passes, oracle C blocks + numpy TFA decoder, %.2f s" % (reps, tc)}
         out["verified"] += "; capture 0 bit-exact vs oracle (sliced bytes, frames)"
     c.close()
     return out
 
 
-def mixed_emitters_workload(torch, dev, skip_cpu, ncap=1250, n=N_PER_CAPTURE, fs=FS, steps=10):
-    """Secondary line: BASELINE.json configs[3] as worded -- a batch of OOK/PWM captures from somfy RTS,
-    berner and mumbi transmitters (one emitter per capture, random payloads; timings of the reference's
-    transmitter.py scripts), channel filter at decimation 10 (100 kS/s sliced stream: the pigpio rules
-    need ~10 us edge resolution), then ALL THREE rule decoders over every capture (sdr_redecode)."""
-    from sdr_amd import chain, synth, _lib
-    rng = np.random.default_rng(4242)
-    D = 10
+def make_mixed_batch(torch, dev, ncap, n=N_PER_CAPTURE, fs=FS, seed=4242):
+    """configs[3] as worded: one somfy RTS / berner / mumbi emitter per capture (timings of the reference's
+    transmitter.py scripts, random payloads), carrier + AWGN applied on the GPU.  -> (iq, [(decoder, payload)])"""
+    from sdr_amd import chain, synth
+    rng = np.random.default_rng(seed)
     env = np.zeros((ncap, n), np.uint8)
     want = []
     codes = sorted(synth.MUMBI_CODES)
@@ -346,7 +423,7 @@ def mixed_emitters_workload(torch, dev, skip_cpu, ncap=1250, n=N_PER_CAPTURE, fs
             want.append((chain.DEC_MUMBI, bytes(bytearray([code[0], code[1], code[2], code[3], code[4] & 0xC0]))))
         env[i] = synth.envelope(sym, fs, lead_in_us=lead + 200.0 * rng.random(), total=n)
     g = torch.Generator(device=dev)
-    g.manual_seed(4242)
+    g.manual_seed(seed)
     iq = torch.empty((ncap, n, 2), dtype=torch.float32, device=dev)
     t = torch.arange(n, dtype=torch.float64, device=dev)
     ph0 = torch.from_numpy(rng.random(ncap) * 2 * np.pi).to(dev)
@@ -357,6 +434,18 @@ def mixed_emitters_workload(torch, dev, skip_cpu, ncap=1250, n=N_PER_CAPTURE, fs
         iq[a:b, :, 0] = e * torch.cos(ph).to(torch.float32)
         iq[a:b, :, 1] = e * torch.sin(ph).to(torch.float32)
         iq[a:b] += 0.02 * torch.randn((b - a, n, 2), generator=g, device=dev, dtype=torch.float32)
+    return iq, want
+
+
+def mixed_emitters_workload(torch, dev, skip_cpu, ncap=1250, n=N_PER_CAPTURE, fs=FS, steps=10):
+    """Secondary line: BASELINE.json configs[3] as worded -- a batch of OOK/PWM captures from somfy RTS,
+    berner and mumbi transmitters (one emitter per capture, random payloads; timings of the reference's
+    transmitter.py scripts), channel filter at decimation 10 (100 kS/s sliced stream: the pigpio rules
+    need ~10 us edge resolution), then ALL THREE rule decoders over every capture (sdr_redecode).
+    The same batch is checked at full size in tests/test_gpu_fullsize.py."""
+    from sdr_amd import chain, synth, _lib
+    D = 10
+    iq, want = make_mixed_batch(torch, dev, ncap, n, fs)
     taps = chain.low_pass(1.0, fs, 20e3, 40e3)
     c = chain.Chain(fs, decim=D, center_freq=F_OFF, taps=taps, decoder=chain.DEC_SOMFY, max_batch=ncap, max_frames=8,
                     max_samples=n)
@@ -415,24 +504,29 @@ def mixed_emitters_workload(torch, dev, skip_cpu, ncap=1250, n=N_PER_CAPTURE, fs
         bits = c.fetch_bits().reshape(ncap, -1)
         sniff = {chain.DEC_SOMFY: (odec.SomfySniffer, 20000), chain.DEC_BERNER: (odec.BernerSniffer, None),
                  chain.DEC_MUMBI: (odec.MumbiSniffer, 8000)}
-        t0 = time.perf_counter()
-        for i in (0, 1, 2):
-            x = iq[i].cpu().numpy().view(np.complex64).reshape(-1)
-            wb = odsp.ook_chain(x, taps, D, 1.0, 0.05, 0.15, 1, fc=F_OFF, fs=fs)
+        xs = [iq[i].cpu().numpy().view(np.complex64).reshape(-1) for i in (0, 1, 2)]
+
+        def cpu_pass():
+            res = []
+            for i in (0, 1, 2):
+                wb = odsp.ook_chain(xs[i], taps, D, 1.0, 0.05, 0.15, 1, fc=F_OFF, fs=fs)
+                cls, wd = sniff[want[i][0]]
+                sn = cls()
+                for lvl, tick in odec.edges_to_events(wb, int(fs / D), watchdog_us=wd):
+                    sn.cbf(lvl, tick)
+                res.append((wb, sn))
+            return res
+        res, reps, tc = timed_repeat(cpu_pass, 2.0)
+        for i, (wb, sn) in enumerate(res):
             if not np.array_equal(bits[i], wb):
                 raise SystemExit("mixed emitters: capture %d sliced bytes differ from the oracle" % i)
-            cls, wd = sniff[want[i][0]]
-            sn = cls()
-            for lvl, tick in odec.edges_to_events(wb, int(fs / D), watchdog_us=wd):
-                sn.cbf(lvl, tick)
             mine = [f for f in got[want[i][0]] if f.capture == i]
             ref = [fr["raw"] if isinstance(fr, dict) else fr for fr in sn.frames]
             have = [bytes(bytearray(f.raw[:7])) if want[i][0] == chain.DEC_SOMFY else f.packet() for f in mine]
             if ref != have:
                 raise SystemExit("mixed emitters: capture %d frames differ from the oracle" % i)
-        tc = time.perf_counter() - t0
-        out["cpu_baseline"] = {"value": round(3 * n / tc / 1e6, 2), "unit": "Msps", "cores": 1, "kind": "port",
-                               "sample": "captures 0-2 (one per emitter), oracle C chain + rule restatements, %.2f s" % tc}
+        out["cpu_baseline"] = {"value": round(reps * 3 * n / tc / 1e6, 2), "unit": "Msps", "cores": 1, "kind": "port",
+                               "sample": "captures 0-2 (one per emitter) x %d passes, oracle C chain + rule restatements, %.2f s" % (reps, tc)}
         out["verified"] += "; captures 0-2 bit-exact vs oracle (sliced bytes and frames)"
     c.close()
     return out
@@ -532,14 +626,14 @@ def pfb_workload(torch, dev, skip_cpu, n=1 << 26, fs=20e6, steps=10):
         m = 1 << 21
         xs = iq[:m].cpu().numpy().view(np.complex64).reshape(-1)
         bits = c.fetch_bits().reshape(M, -1)
-        t0 = time.perf_counter()
-        y = odsp.pfb_channelize(xs, taps, M)
-        want = np.stack([odsp.slice_bits(odsp.mag2(y[k]), 1.0, 0.05, 0.15, keep)[0] for k in range(M)])
-        tc = time.perf_counter() - t0
+        def cpu_pass():
+            y = odsp.pfb_channelize(xs, taps, M)
+            return np.stack([odsp.slice_bits(odsp.mag2(y[k]), 1.0, 0.05, 0.15, keep)[0] for k in range(M)])
+        want, reps, tc = timed_repeat(cpu_pass, 2.0)
         if not np.array_equal(bits[:, :want.shape[1]], want):
             raise SystemExit("channelizer: sliced bytes of the first 2^21 samples differ from the oracle")
-        out["cpu_baseline"] = {"value": round(m / tc / 1e6, 2), "unit": "Msps", "cores": 1, "kind": "port",
-                               "sample": "first 2^21 samples, oracle C channelizer + slicer, %.2f s" % tc}
+        out["cpu_baseline"] = {"value": round(reps * m / tc / 1e6, 2), "unit": "Msps", "cores": 1, "kind": "port",
+                               "sample": "first 2^21 samples x %d passes, oracle C channelizer + slicer, %.2f s" % (reps, tc)}
         out["verified"] += "; all 64 sliced streams of the first 2^21 samples bit-exact vs oracle"
     c.close()
     return out
@@ -636,7 +730,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--captures", type=int, default=1250, help="captures per GPU (configs[3]: 10000 / 8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-worker", nargs=4, metavar=("NPY", "FIRST", "COUNT", "SECONDS"), help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.cpu_worker:
+        return cpu_worker(args.cpu_worker[0], int(args.cpu_worker[1]), int(args.cpu_worker[2]), float(args.cpu_worker[3]))
     rehearsal = os.environ.get("SDR_BENCH_REHEARSAL") == "gloo"
     if args.gpus < 1:
         raise SystemExit("bench.py: --gpus must be >= 1")
