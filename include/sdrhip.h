@@ -209,6 +209,13 @@ SDR_API int sdr_process_iq(sdr_handle* h, const void* iq, size_t n, int is_devic
  * bits = n int8 values 0/1 at the decoder rate. */
 SDR_API int sdr_process_bits(sdr_handle* h, const int8_t* bits, size_t n, int is_device_ptr, sdr_out* out);
 
+/* Decoder-only batch: `rows` independent sliced streams of n bytes each (row r at bits + r*stride, host or
+ * device), every one decoded by a fresh decoder as ONE work() call.
+ * ref: TS33C/stream_decoder.py:222-235 main() with a single chunk, per recorded .dat file; used to decode
+ * the stitched channel rows of a wideband capture that was channelized in segments (sdr_seek). */
+SDR_API int sdr_batch_process_bits(sdr_handle* h, const int8_t* bits, size_t n, size_t stride, int rows,
+                                   int is_device_ptr, sdr_out* out);
+
 /* ---- batch entry point -----------------------------------------------------
  * n_captures independent captures of n_per_capture samples each (capture i at
  * iq + i*stride samples), every one processed from stream start by a fresh
@@ -311,6 +318,9 @@ typedef struct sdr_segment_info {
 } sdr_segment_info;
 /* summary of the last sdr_process_iq call (synchronises) */
 SDR_API int sdr_segment_info_get(sdr_handle* h, sdr_segment_info* info);
+/* the same summary for every row of the last call (a channelizer handle: 64 channel rows that share
+ * first_bit_index / n_bits and differ in the threshold fields); info may be NULL to query *n. */
+SDR_API int sdr_segment_info_rows(sdr_handle* h, sdr_segment_info* info, size_t cap, size_t* n);
 /* the last call's sliced bytes (capture-major, dense) into a caller-owned DEVICE
  * buffer on the handle's stream, ready for a collective; *n = bytes written. */
 SDR_API int sdr_export_bits(sdr_handle* h, void* bits_dev, size_t cap_bytes, size_t* n);
@@ -326,7 +336,12 @@ SDR_API int sdr_export_bits(sdr_handle* h, void* bits_dev, size_t cap_bytes, siz
  * The handle is used like a batch chain: sdr_set_taps (prototype low-pass, real,
  * <= 1024 taps), sdr_batch_process (whole captures from stream start),
  * sdr_fetch_*: row r = capture*64 + channel (channel c is centred at c*fs/64,
- * c >= 32 are the negative frequencies); sdr_frame.capture holds that row. */
+ * c >= 32 are the negative frequencies); sdr_frame.capture holds that row.
+ * A handle created with max_batch 1 also STREAMS one wideband capture: sdr_process_iq
+ * takes chunks of any length (the (P-1)*64+63-sample filter history, the 64-sample output
+ * phase, the keep_one_in_n counter and, per channel row, the threshold bit and the
+ * decoder / rule state persist), sdr_seek positions it on a segment of a long capture and
+ * sdr_segment_info_rows reports the per-channel threshold summary for the stitch. */
 SDR_API int sdr_pfb_create(const sdr_chain_cfg* cfg, int channels, sdr_handle** out);
 /* Decode the sliced bytes of the last sdr_batch_process again with another
  * decoder (SDR_DEC_*, decoder_rate 0 = unchanged): "all sensor decoders run

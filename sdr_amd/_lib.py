@@ -153,7 +153,7 @@ EXPORTS = [
     "sdr_fm_create", "sdr_fm_destroy", "sdr_fm_set_stream", "sdr_fm_process", "sdr_fm_fetch",
     "sdr_fm_last_error",
     "sdr_pfb_create", "sdr_redecode", "sdr_set_input_format", "sdr_history_len", "sdr_seek", "sdr_segment_info_get", "sdr_export_bits",
-    "sdr_batch_process_static", "sdr_static_scratch_bytes",
+    "sdr_batch_process_static", "sdr_static_scratch_bytes", "sdr_segment_info_rows", "sdr_batch_process_bits",
 ]
 
 _lib = None
@@ -257,6 +257,10 @@ def load():
     L.sdr_seek.argtypes = [H, C.c_uint64, C.c_void_p, C.c_size_t, C.c_int]
     L.sdr_segment_info_get.restype = C.c_int
     L.sdr_segment_info_get.argtypes = [H, C.POINTER(SegmentInfo)]
+    L.sdr_segment_info_rows.restype = C.c_int
+    L.sdr_segment_info_rows.argtypes = [H, C.POINTER(SegmentInfo), C.c_size_t, C.POINTER(C.c_size_t)]
+    L.sdr_batch_process_bits.restype = C.c_int
+    L.sdr_batch_process_bits.argtypes = [H, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.POINTER(Out)]
     L.sdr_export_bits.restype = C.c_int
     L.sdr_export_bits.argtypes = [H, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.sdr_batch_process_static.restype = C.c_int

@@ -266,6 +266,31 @@ class Chain(object):
         _lib.check(self._h, self._L.sdr_segment_info_get(self._h, C.byref(info)))
         return info
 
+    def segment_info_rows(self):
+        """per-row summaries of the last call (channelizer: one per channel)"""
+        n = C.c_size_t()
+        _lib.check(self._h, self._L.sdr_segment_info_rows(self._h, None, 0, C.byref(n)))
+        buf = (_lib.SegmentInfo * max(1, n.value))()
+        if n.value:
+            _lib.check(self._h, self._L.sdr_segment_info_rows(self._h, buf, n.value, C.byref(n)))
+        return [buf[i] for i in range(n.value)]
+
+    def batch_process_bits(self, bits):
+        """Decoder only: rows of sliced bytes, shape (rows, n) -- numpy int8/uint8 or a torch tensor on the GPU --
+        each decoded by a fresh decoder as one work() call; then fetch_frames()."""
+        if _is_torch(bits) and bits.is_cuda:
+            if bits.dim() != 2 or bits.element_size() != 1 or bits.stride(1) != 1:
+                raise ValueError("bits tensor must be 2-D int8/uint8 with contiguous rows")
+            _lib.check(self._h, self._L.sdr_batch_process_bits(self._h, C.c_void_p(bits.data_ptr()), int(bits.shape[1]),
+                                                               int(bits.stride(0)), int(bits.shape[0]), 1, C.byref(self.out)))
+            return self.out
+        b = np.ascontiguousarray(bits, np.int8)
+        if b.ndim != 2:
+            raise ValueError("bits must be 2-D (rows, n)")
+        _lib.check(self._h, self._L.sdr_batch_process_bits(self._h, C.c_void_p(b.ctypes.data), b.shape[1], b.shape[1],
+                                                           b.shape[0], 0, C.byref(self.out)))
+        return self.out
+
     def export_bits(self, bits_tensor):
         """Last call's sliced bytes into a torch uint8/int8 tensor on this GPU; -> count."""
         n = C.c_size_t()

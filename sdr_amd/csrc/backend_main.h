@@ -380,7 +380,7 @@ __global__ void __launch_bounds__(BK_THREADS, 6) k_backend(BackParams P)
     const bool stream_dec = P.decoder <= SDR_DEC_TFA_GRC;
     const int32_t* rpos = pos_in_lds ? s_pos : pos;
     // streaming rule decoders: ticks are absolute, the callback's state comes from / goes to P.rule
-    RuleState* const rs = (!stream_dec && P.decoder != SDR_DEC_VELUX && cap == 0) ? P.rule : nullptr;
+    RuleState* const rs = (!stream_dec && P.decoder != SDR_DEC_VELUX && P.rule) ? P.rule + cap : nullptr;
     const long long rule_base = (rs && rs->valid) ? rs->base : 0;
     if (w_in_lds) {
         if (stream_dec)

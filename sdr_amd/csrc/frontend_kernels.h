@@ -38,51 +38,29 @@ __device__ __forceinline__ float2 nco_eval(const float2* __restrict__ tab, unsig
     return o;
 }
 
-// gnuradio fast_atan2f restated (table 257 floats), same op order as the oracle
+// gnuradio fast_atan2f restated (table 257 floats): the oracle's arithmetic (one division, the table
+// lerp as sub / mul / add, one add or subtract of the octant constant), written without branches --
+// the if/else ladder of the original compiled to ~30 basic blocks of exec masking per call.  The
+// selects reproduce the ladder exactly: its eight outcomes are +-(c + s*base) with c in {0, pi, pi/2}
+// and s = +-1, and IEEE negation is exact (a - b == -(b - a), c + (-b) == c - b; none of these sums
+// can be zero since base <= ~pi/4 < c, so no signed-zero case arises; 0 + base == base).
 __device__ __forceinline__ float fast_atan2f_dev(const float* __restrict__ tab, float y, float x)
 {
-    float y_abs = __builtin_fabsf(y), x_abs = __builtin_fabsf(x), z, base;
-    if (!((y_abs > 0.0f) || (x_abs > 0.0f))) return 0.0f;
-    if (y_abs < x_abs)
-        z = y_abs / x_abs;
-    else
-        z = x_abs / y_abs;
-    if (z < 0.003921569f)
-        base = z;
-    else {
-        float alpha = z * 255.0f;
-        int index = ((int)alpha) & 0xff;
-        alpha -= (float)index;
-        base = tab[index];
-        base += (tab[index + 1] - tab[index]) * alpha;
-    }
-    float angle;
-    if (x_abs > y_abs) {
-        if (x >= 0.0f)
-            angle = (y >= 0.0f) ? base : -base;
-        else {
-            angle = 3.14159265358979323846f;
-            if (y >= 0.0f)
-                angle -= base;
-            else
-                angle = base - angle;
-        }
-    } else {
-        if (y >= 0.0f) {
-            angle = 1.57079632679489661923f;
-            if (x >= 0.0f)
-                angle -= base;
-            else
-                angle += base;
-        } else {
-            angle = -1.57079632679489661923f;
-            if (x >= 0.0f)
-                angle += base;
-            else
-                angle -= base;
-        }
-    }
-    return angle;
+    const float y_abs = __builtin_fabsf(y), x_abs = __builtin_fabsf(x);
+    const bool ylt = y_abs < x_abs;
+    const float z = (ylt ? y_abs : x_abs) / (ylt ? x_abs : y_abs);
+    float alpha = z * 255.0f;
+    const int index = ((int)alpha) & 0xff;
+    alpha -= (float)index;
+    const float t0 = tab[index], t1 = tab[index + 1];
+    float base = t0 + (t1 - t0) * alpha;
+    base = (z < 0.003921569f) ? z : base;
+    const bool xdom = x_abs > y_abs, xpos = x >= 0.0f;
+    const float c = xdom ? (xpos ? 0.0f : 3.14159265358979323846f) : 1.57079632679489661923f;
+    const float sb = (xdom != xpos) ? -base : base;    // xdom: minus iff x < 0;  otherwise: minus iff x >= 0
+    const float r = c + sb;
+    const float angle = (y >= 0.0f) ? r : -r;
+    return ((y_abs > 0.0f) || (x_abs > 0.0f)) ? angle : 0.0f;
 }
 
 // Hysteresis (threshold_ff) inside one tile as a scan over {set, clear, hold}

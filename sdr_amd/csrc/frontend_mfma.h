@@ -28,9 +28,11 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// Hysteresis + slicer for N consecutive outputs per thread (see slice_tile).
+// Hysteresis + slicer for N consecutive outputs per thread (see slice_tile).  i0 = index inside the tile
+// of the thread's first output (o_base = output index of the tile's index 0): everything per lane is
+// 32-bit, the 64-bit parts are wave-uniform.
 template <int N>
-__device__ __forceinline__ void slice_tile_xn(const bool* valid, const float* v, long long o_first, long long o_base,
+__device__ __forceinline__ void slice_tile_xn(const bool* valid, const float* v, int i0, long long o_base,
                                               float lo, float hi, int keep_n, long long keep_c0,
                                               int8_t* __restrict__ bits, TileSum* __restrict__ ts_out,
                                               int* __restrict__ sh /* 12 ints */)
@@ -76,9 +78,26 @@ __device__ __forceinline__ void slice_tile_xn(const bool* valid, const float* v,
         ts_out->first_evt = first < 0 ? -1 : (int32_t)(o_base + first);
         ts_out->last_state = lst;
     }
+    const long long ub = o_base - keep_c0;   // uniform: emitted-byte index of the tile's index 0 (keep_n == 1)
+    if (keep_n == 1 && ub >= 0) {           // every tile but a stream's first: no per-lane 64-bit arithmetic
+        int8_t* __restrict__ pb = bits + ub;
+#pragma unroll
+        for (int e = 0; e < N; ++e) {
+            if (evt[e] == 1)
+                st = 1;
+            else if (evt[e] == 2)
+                st = 0;
+#if defined(WIN_ABL) && WIN_ABL == 3
+            if (valid[e] && st == 77) pb[i0 + e] = (int8_t)st;
+#else
+            if (valid[e]) pb[i0 + e] = (int8_t)st;
+#endif
+        }
+        return;
+    }
     // keep_one_in_n: one division per thread (32-bit when the index allows), then
     // the remainder is stepped along the thread's N outputs
-    const long long r0 = o_first - keep_c0;
+    const long long r0 = ub + i0;
     long long quo = 0;
     int rem = 0;
     if (keep_n > 1 && r0 + (N - 1) >= 0) {
@@ -291,15 +310,15 @@ __global__ void __launch_bounds__(256) k_frontend_mfma(FrontParams P)
         __syncthreads();
         ybuf[4 * t + 3] = make_float2(ar[3], ai[3]);
         __syncthreads();
+        const float2 pv0 = t ? ybuf[4 * t - 1] : make_float2(0.f, 0.f);   // thread 0's e = 0 is never valid (q = 1)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            v[e] = 0.f;
-            if (valid[e]) {
-                const float2 pv = (e == 0) ? ybuf[4 * t - 1] : make_float2(ar[e - 1], ai[e - 1]);
-                const float tr = __builtin_fmaf(ar[e], pv.x, ai[e] * pv.y);
-                const float ti = __builtin_fmaf(ai[e], pv.x, -(ar[e] * pv.y));
-                v[e] = fast_atan2f_dev(s_atan, ti, tr);
-            }
+            // every lane and output (no exec-masked block per output); valid[] drops what is not emitted
+            const float2 pv = (e == 0) ? pv0 : make_float2(ar[e - 1], ai[e - 1]);
+            const float tr = __builtin_fmaf(ar[e], pv.x, ai[e] * pv.y);
+            const float ti = __builtin_fmaf(ai[e], pv.x, -(ar[e] * pv.y));
+            const float a = fast_atan2f_dev(s_atan, ti, tr);
+            v[e] = valid[e] ? a : 0.f;
         }
     }
 #pragma unroll
@@ -311,6 +330,6 @@ __global__ void __launch_bounds__(256) k_frontend_mfma(FrontParams P)
             if (valid[e]) dst[m0 + e] = v[e];
     }
     if (!P.do_slice) return;
-    slice_tile_xn<4>(valid, v, m0, m_t0, P.lo, P.hi, P.keep_n, P.keep_c0, P.bits + (long long)cap * P.bits_stride,
+    slice_tile_xn<4>(valid, v, 4 * t, m_t0, P.lo, P.hi, P.keep_n, P.keep_c0, P.bits + (long long)cap * P.bits_stride,
                   P.tsum + (long long)cap * P.tiles_per_capture + tile, sh);
 }

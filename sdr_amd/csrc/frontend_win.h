@@ -29,20 +29,14 @@ __host__ __device__ inline int win_sample_slots(int T, int ntaps)
     return T * WIN_R + ((ntaps + 1 + WIN_W - 1) / WIN_W) * WIN_W + WIN_W + 2;
 }
 
-// blockDim.x = T (64 or 256), P.D == 1, real taps, P.tile_out = T*WIN_R - q.
-__global__ void __launch_bounds__(256) k_frontend_win(FrontParams P)
+// One tile: blockDim.x = T (64 or 256) threads, T*WIN_R - q outputs.
+__device__ __forceinline__ void win_tile(const FrontParams& P, const int tile, const int cap, unsigned char* smem_raw,
+                                         int* sh, const float* s_atan, float2* s_edge)
 {
-    extern __shared__ __align__(16) unsigned char smem_raw[];
-    __shared__ int sh[12];
-    __shared__ float s_atan[257];
-    __shared__ float2 s_edge[4];
     constexpr int R = WIN_R, W = WIN_W;
     const int T = blockDim.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int tile = blockIdx.x, cap = blockIdx.y;
     const int nt = P.ntaps, H = nt - 1;
     const int q = (P.demod == SDR_DEMOD_QUAD) ? 1 : 0;
-    if (q)
-        for (int i = t; i < 257; i += T) s_atan[i] = P.atan_tab[i];
     const int ntl = win_tap_floats(nt);
     float* const tapL = reinterpret_cast<float*>(smem_raw);
     float2* const lds = reinterpret_cast<float2*>(tapL + ntl);
@@ -67,11 +61,18 @@ __global__ void __launch_bounds__(256) k_frontend_win(FrontParams P)
         const long long lo_al = lo_idx - odd;
         const int pairs = (count + odd + 1) >> 1;
         lsh = odd;
+        // chunk p holds samples lo_al + 2p, +1: inside the capture for p in [plo, phi) -- uniform bounds,
+        // so a lane tests two 32-bit numbers and adds a 32-bit offset to a uniform base
+        long long plo64 = lo_al < 0 ? (1 - lo_al) >> 1 : 0, phi64 = (P.n - lo_al) >> 1;
+        if (plo64 > pairs) plo64 = pairs;
+        if (phi64 > pairs) phi64 = pairs;
+        if (phi64 < plo64) phi64 = plo64;
+        const int plo = (int)plo64, phi = (int)phi64;
+        const char* __restrict__ xb = reinterpret_cast<const char*>(x + lo_al);
         for (int p0 = (t & ~63); p0 < pairs; p0 += T) {
             const int p = p0 + lane;
-            const long long s = lo_al + 2LL * p;
-            if (p < pairs && s >= 0 && s + 2 <= P.n)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(x + s),
+            if (p >= plo && p < phi)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xb + (unsigned)(16 * p)),
                                                  (__attribute__((address_space(3))) void*)(lds + 2 * p0), 16, 0,
                                                  SDR_GLDS_AUX);
         }
@@ -102,6 +103,9 @@ __global__ void __launch_bounds__(256) k_frontend_win(FrontParams P)
         tapL[i] = (idx >= 0 && idx < nt) ? P.rtaps[idx] : 0.f;
     }
     __syncthreads();
+#if defined(WIN_ABL) && WIN_ABL == 4
+    if (P.ntaps > 0) return;
+#endif
 
     // ---- sliding-window FIR.  The packed fmas are written out (v_pk_fma_f32: one IEEE fma per
     // component, the same rounding as two fmaf calls) so that the tap can be taken from either half of
@@ -125,7 +129,12 @@ __global__ void __launch_bounds__(256) k_frontend_win(FrontParams P)
         }
 #define WIN_FMA_LO(A, TP, X) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(A) : "v"(TP), "v"(X))
 #define WIN_FMA_HI(A, TP, X) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(A) : "v"(TP), "v"(X))
+#if defined(WIN_ABL) && WIN_ABL == 1
+        for (int r = 0; r < R; ++r) acc[r] = w[r];
+        for (int j0 = 0; j0 < 0; j0 += W) {
+#else
         for (int j0 = 0; j0 < jhi; j0 += W) {
+#endif
             v2f tp[W / 2];   // tap pairs (t[2k], t[2k+1])
 #pragma unroll
             for (int k = 0; k < W / 4; ++k) {
@@ -157,15 +166,19 @@ __global__ void __launch_bounds__(256) k_frontend_win(FrontParams P)
 #undef WIN_FMA_HI
     }
 
-    // ---- epilogue: thread t owns outputs R*t .. R*t+R-1 of the tile
+    // ---- epilogue: thread t owns outputs R*t .. R*t+R-1 of the tile (tile-relative index i: FIR output
+    // m_t0 + i).  An output exists for i in [i_lo, i_hi) (m >= 0 or streaming history, m < nout) and is
+    // emitted for i in [q, i_hi): uniform 32-bit limits instead of 64-bit compares per lane and output.
     const long long m0 = m_t0 + (long long)R * t;
+    const long long left = P.nout - m_t0;
+    const int i_hi = left > (long long)T * R ? T * R : (left < 0 ? 0 : (int)left);
+    const int i_lo = (P.hist != nullptr || m_t0 >= 0) ? 0 : (int)(-m_t0);
     bool valid[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        const long long m = m0 + r;
-        const bool have_y = (m >= 0 || P.hist != nullptr) && (m < P.nout);
-        if (!have_y) acc[r] = (v2f){0.f, 0.f};
-        valid[r] = (R * t + r >= q) && (m < P.nout);
+        const int i = R * t + r;
+        if (!(i >= i_lo && i < i_hi)) acc[r] = (v2f){0.f, 0.f};
+        valid[r] = i >= q && i < i_hi;
     }
     if (P.demod == SDR_DEMOD_NONE) {
         if (P.tap) {
@@ -190,13 +203,17 @@ __global__ void __launch_bounds__(256) k_frontend_win(FrontParams P)
         if (lane == 0) pv = wave ? s_edge[wave - 1] : make_float2(0.f, 0.f);
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            v[r] = 0.f;
+            // computed for every lane and output (no exec-masked block per output); outputs that do not
+            // exist have zero accumulators, the ones not emitted are dropped by valid[] below
             const float2 pr = r ? make_float2(acc[r - 1].x, acc[r - 1].y) : pv;
-            if (valid[r]) {
-                const float tr = __builtin_fmaf(acc[r].x, pr.x, acc[r].y * pr.y);
-                const float ti = __builtin_fmaf(acc[r].y, pr.x, -(acc[r].x * pr.y));
-                v[r] = fast_atan2f_dev(s_atan, ti, tr);
-            }
+            const float tr = __builtin_fmaf(acc[r].x, pr.x, acc[r].y * pr.y);
+            const float ti = __builtin_fmaf(acc[r].y, pr.x, -(acc[r].x * pr.y));
+#if defined(WIN_ABL) && WIN_ABL == 2
+            const float a = ti + tr;
+#else
+            const float a = fast_atan2f_dev(s_atan, ti, tr);
+#endif
+            v[r] = valid[r] ? a : 0.f;
         }
     }
 #pragma unroll
@@ -208,6 +225,21 @@ __global__ void __launch_bounds__(256) k_frontend_win(FrontParams P)
             if (valid[r]) dst[m0 + r] = v[r];
     }
     if (!P.do_slice) return;
-    slice_tile_xn<R>(valid, v, m0, m_t0, P.lo, P.hi, P.keep_n, P.keep_c0, P.bits + (long long)cap * P.bits_stride,
+    slice_tile_xn<R>(valid, v, R * t, m_t0, P.lo, P.hi, P.keep_n, P.keep_c0, P.bits + (long long)cap * P.bits_stride,
                      P.tsum + (long long)cap * P.tiles_per_capture + tile, sh);
+}
+
+// blockDim.x = T (64 or 256), P.D == 1, real taps, P.tile_out = T*WIN_R - q; one tile per workgroup.
+// (A workgroup walking 2..16 consecutive tiles was measured and dropped: no faster at any count -- the
+// kernel is bound by its VALU instruction count, not by workgroup dispatch -- and the loop-carried
+// values cost 40 VGPRs, i.e. two resident waves per SIMD.)
+__global__ void __launch_bounds__(256) k_frontend_win(FrontParams P)
+{
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    __shared__ int sh[12];
+    __shared__ float s_atan[257];
+    __shared__ float2 s_edge[4];
+    if (P.demod == SDR_DEMOD_QUAD)
+        for (int i = threadIdx.x; i < 257; i += blockDim.x) s_atan[i] = P.atan_tab[i];
+    win_tile(P, blockIdx.x, blockIdx.y, smem_raw, sh, s_atan, s_edge);
 }

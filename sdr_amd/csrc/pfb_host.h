@@ -22,7 +22,19 @@ static int pfb_upload_taps(sdr_handle* h)
     HIPCHK(h, dev_alloc((void**)&h->d_pfb_taps, t.size() * sizeof(float)));
     HIPCHK(h, hipMemcpy(h->d_pfb_taps, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice));
     h->pfb_P = P;
-    return SDR_OK;
+    // streaming history as for a decimating FIR of P*64 taps: ntaps-1 + 2*D samples
+    h->hist_len = P * M - 1 + 2 * M;
+    if (h->hist_len > h->hist_cap) {
+        for (int i = 0; i < 2; ++i) {
+            if (h->d_hist[i]) (void)hipFree(h->d_hist[i]);
+            h->d_hist[i] = nullptr;
+            HIPCHK(h, dev_alloc((void**)&h->d_hist[i], (size_t)h->hist_len * sizeof(float2)));
+        }
+        h->hist_cap = h->hist_len;
+    }
+    for (int i = 0; i < 2; ++i) HIPCHK(h, hipMemset(h->d_hist[i], 0, (size_t)h->hist_cap * sizeof(float2)));
+    reset_stream_counters(h);
+    return reset_dec_state(h);
 }
 
 extern "C" int sdr_pfb_create(const sdr_chain_cfg* cfg, int channels, sdr_handle** out)
@@ -61,6 +73,67 @@ extern "C" int sdr_pfb_create(const sdr_chain_cfg* cfg, int channels, sdr_handle
     return SDR_OK;
 }
 
+// k_pfb over `ncap` captures (batch) or one streaming call: nout outputs per channel row, bits written
+// from patch_off on in every row
+static int pfb_launch(sdr_handle* h, const float2* x, long long stride, long long n, int ncap, const CallGeom& g,
+                      const float2* hist, int hist_len, long long patch_off)
+{
+    const sdr_chain_cfg& c = h->cfg;
+    if (g.tiles > h->tsum_stride) return fail(h, SDR_E_CAPACITY, "tile table too small");
+    if (g.nout >= 0x7fffffffLL) return fail(h, SDR_E_CAPACITY, "capture too long for the channelizer");
+    if (c.demod == SDR_DEMOD_NONE && !h->d_tap)
+        return fail(h, SDR_E_ARG, "demod NONE needs cfg.tap_demod (complex output buffer)");
+    if (g.nout <= 0) return SDR_OK;
+    PfbParams Q;
+    memset(&Q, 0, sizeof Q);
+    Q.x = x;
+    Q.hist = hist;
+    Q.hist_len = hist_len;
+    Q.in0 = g.in0;
+    Q.stride = stride;
+    Q.n = n;
+    Q.nout = g.nout;
+    Q.vec_ok = ((((uintptr_t)x) & 15) == 0 && (stride % 2) == 0) ? 1 : 0;
+    Q.taps = h->d_pfb_taps;
+    Q.tw = h->d_pfb_tw;
+    Q.demod = c.demod;
+    Q.gain = c.demod_gain;
+    Q.lo = c.thr_lo;
+    Q.hi = c.thr_hi;
+    Q.keep_n = c.keep_n;
+    Q.keep_c0 = g.keep_c0;
+    Q.bits = h->d_bits + patch_off;
+    Q.bits_stride = h->bits_stride;
+    Q.tap = (c.tap_demod || c.demod == SDR_DEMOD_NONE) ? h->d_tap : nullptr;
+    Q.tap_stride = h->tap_stride;
+    Q.tsum = h->d_tsum;
+    Q.tiles_per_row = g.tiles;
+    size_t lds = ((size_t)(h->pfb_P + PFB_TILE - 1) * PFB_M + 2) * sizeof(float2);
+    if (lds < (size_t)PFB_NW * PFB_SLAB * sizeof(float2)) lds = (size_t)PFB_NW * PFB_SLAB * sizeof(float2);
+    dim3 grid(g.tiles, ncap), block(256);
+    switch (h->pfb_P) {
+    case 4: hipLaunchKernelGGL(k_pfb<4>, grid, block, lds, h->stream, Q); break;
+    case 8: hipLaunchKernelGGL(k_pfb<8>, grid, block, lds, h->stream, Q); break;
+    default: hipLaunchKernelGGL(k_pfb<16>, grid, block, lds, h->stream, Q); break;
+    }
+    HIPCHK(h, hipGetLastError());
+    return SDR_OK;
+}
+
+static void pfb_geom(const sdr_handle* h, long long nout, long long in0, long long keep_c0, CallGeom& g)
+{
+    memset(&g, 0, sizeof g);
+    const long long kn = h->cfg.keep_n;
+    g.nout = nout;
+    g.in0 = in0;
+    g.keep_c0 = keep_c0;
+    g.ne = nout > keep_c0 ? (nout - keep_c0 + kn - 1) / kn : 0;
+    g.T = 256;
+    g.tile_out = PFB_TILE;
+    g.tiles = (int)((nout + PFB_TILE - 1) / PFB_TILE);
+    g.use_lds = true;
+}
+
 static int pfb_batch(sdr_handle* h, const void* iq, size_t n, size_t stride, int ncap, int is_dev, sdr_out* out)
 {
     const sdr_chain_cfg& c = h->cfg;
@@ -79,55 +152,14 @@ static int pfb_batch(sdr_handle* h, const void* iq, size_t n, size_t stride, int
         x = h->d_iq;
     }
     CallGeom g;
-    memset(&g, 0, sizeof g);
-    g.nout = (long long)(n / M);
-    g.keep_c0 = c.keep_n - 1;
-    g.ne = g.nout > g.keep_c0 ? (g.nout - g.keep_c0 + c.keep_n - 1) / c.keep_n : 0;
-    g.T = 256;
-    g.tile_out = PFB_TILE;
-    g.tiles = (int)((g.nout + PFB_TILE - 1) / PFB_TILE);
-    g.use_lds = true;
-    if (g.tiles > h->tsum_stride) return fail(h, SDR_E_CAPACITY, "tile table too small");
-    if (g.nout >= 0x7fffffffLL) return fail(h, SDR_E_CAPACITY, "capture too long for the channelizer");
-    if (c.demod == SDR_DEMOD_NONE && !h->d_tap)
-        return fail(h, SDR_E_ARG, "demod NONE needs cfg.tap_demod (complex output buffer)");
+    pfb_geom(h, (long long)(n / M), 0, c.keep_n - 1, g);
     if (h->profile) HIPCHK(h, hipEventRecord(h->pev[3 * (h->pcount % SDR_PROF_RING)], h->stream));
-    if (g.nout > 0) {
-        PfbParams Q;
-        memset(&Q, 0, sizeof Q);
-        Q.x = x;
-        Q.stride = (long long)stride;
-        Q.n = (long long)n;
-        Q.nout = g.nout;
-        Q.vec_ok = ((((uintptr_t)x) & 15) == 0 && (stride % 2) == 0) ? 1 : 0;
-        Q.taps = h->d_pfb_taps;
-        Q.tw = h->d_pfb_tw;
-        Q.demod = c.demod;
-        Q.gain = c.demod_gain;
-        Q.lo = c.thr_lo;
-        Q.hi = c.thr_hi;
-        Q.keep_n = c.keep_n;
-        Q.keep_c0 = g.keep_c0;
-        Q.bits = h->d_bits;
-        Q.bits_stride = h->bits_stride;
-        Q.tap = (c.tap_demod || c.demod == SDR_DEMOD_NONE) ? h->d_tap : nullptr;
-        Q.tap_stride = h->tap_stride;
-        Q.tsum = h->d_tsum;
-        Q.tiles_per_row = g.tiles;
-        size_t lds = ((size_t)(h->pfb_P + PFB_TILE - 1) * PFB_M + 2) * sizeof(float2);
-        if (lds < (size_t)PFB_NW * PFB_SLAB * sizeof(float2)) lds = (size_t)PFB_NW * PFB_SLAB * sizeof(float2);
-        dim3 grid(g.tiles, ncap), block(256);
-        switch (h->pfb_P) {
-        case 4: hipLaunchKernelGGL(k_pfb<4>, grid, block, lds, h->stream, Q); break;
-        case 8: hipLaunchKernelGGL(k_pfb<8>, grid, block, lds, h->stream, Q); break;
-        default: hipLaunchKernelGGL(k_pfb<16>, grid, block, lds, h->stream, Q); break;
-        }
-        HIPCHK(h, hipGetLastError());
-    }
+    int r = pfb_launch(h, x, (long long)stride, (long long)n, ncap, g, nullptr, 0, 0);
+    if (r) return r;
     int run = 1;
     if (is_stream_decoder(c.decoder))
         run = ((double)g.ne * 1e6 / h->dec_rate > decoder_reset_limit(c.decoder)) ? 1 : 0;
-    int r = launch_back(h, ncap * M, g, 0, g.ne, 1, 0, run);
+    r = launch_back(h, ncap * M, g, 0, g.ne, 1, 0, run);
     if (r) return r;
     h->last_ncap = ncap * M;
     h->last_nb = g.ne;
@@ -136,6 +168,76 @@ static int pfb_batch(sdr_handle* h, const void* iq, size_t n, size_t stride, int
     h->last_keep_c0 = g.keep_c0;
     h->last_out0 = 0;
     return finish_out(h, out, (unsigned long long)n * ncap, g.ne);
+}
+
+// One streaming call on a channelizer handle (max_batch == 64 rows: one wideband stream): the 64 channel
+// rows advance together -- same FIR history ((P-1)*64+63 input samples and the 64-sample output phase),
+// same keep_one_in_n counter and rawBuffer fill; threshold bit, decoder and rule state are per row.
+static int pfb_stream(sdr_handle* h, const void* iq, size_t n, int is_dev, sdr_out* out)
+{
+    const sdr_chain_cfg& c = h->cfg;
+    const int M = h->pfb_M;
+    if (c.max_batch != M) return fail(h, SDR_E_ARG, "sdr_process_iq: a channelizer streams ONE wideband capture (create it with max_batch 1)");
+    if (n > c.max_samples) return fail(h, SDR_E_CAPACITY, "sdr_process_iq: chunk larger than max_samples");
+    if (h->in_fmt != SDR_IN_FC32) return fail(h, SDR_E_ARG, "channelizer: complex64 input only");
+    (void)hipSetDevice(h->device);
+    const float2* x = (const float2*)iq;
+    if (!is_dev && n) {
+        int r = ensure_iq_staging(h, n);
+        if (r) return r;
+        HIPCHK(h, hipMemcpyAsync(h->d_iq, iq, n * sizeof(float2), hipMemcpyHostToDevice, h->stream));
+        x = h->d_iq;
+    }
+    const unsigned long long A = h->in_count;
+    const unsigned long long m_end = (A + n) / (unsigned long long)M;
+    const long long nout = (long long)(m_end - h->out_count);
+    CallGeom g;
+    pfb_geom(h, nout, (long long)(h->out_count * M) - (long long)A, h->keep_ctr - 1, g);
+    const long long total = h->raw_n + g.ne;
+    if (total > h->bits_stride) return fail(h, SDR_E_CAPACITY, "rawBuffer capacity exceeded");
+    int run = 0;
+    if (is_stream_decoder(c.decoder))
+        run = ((double)total * 1e6 / h->dec_rate > decoder_reset_limit(c.decoder)) ? 1 : 0;
+    else if (c.decoder != SDR_DEC_NONE)
+        run = 1;
+    const long long off = is_stream_decoder(c.decoder) ? h->raw_n : 0;
+    const long long nb_total = off == 0 ? g.ne : total;
+    if (h->profile) HIPCHK(h, hipEventRecord(h->pev[3 * (h->pcount % SDR_PROF_RING)], h->stream));
+    int r = pfb_launch(h, x, 0, (long long)n, 1, g, hist_ptr(h), hist_valid(h), off);
+    if (r) return r;
+    r = launch_back(h, M, g, off, nb_total, 0, 1, run);
+    if (r) return r;
+    h->last_ncap = M;
+    h->last_nb = g.ne;
+    h->last_nout = g.nout;
+    h->last_bits_off = off;
+    h->last_keep_c0 = g.keep_c0;
+    h->last_out0 = h->out_count;
+    h->carry_last = h->carry_next;
+    h->carry_next = -1;
+    if (is_stream_decoder(c.decoder)) h->raw_n = run ? 0 : total;
+    if (n) {
+        const size_t H = (size_t)h->hist_len, ss = sizeof(float2);
+        const char* xb = reinterpret_cast<const char*>(x);
+        char* cur = reinterpret_cast<char*>(h->d_hist[h->hist_sel]);
+        char* nxt = reinterpret_cast<char*>(h->d_hist[h->hist_sel ^ 1]);
+        if (n >= H)
+            HIPCHK(h, hipMemcpyAsync(nxt, xb + (n - H) * ss, H * ss, hipMemcpyDeviceToDevice, h->stream));
+        else {
+            HIPCHK(h, hipMemcpyAsync(nxt, cur + n * ss, (H - n) * ss, hipMemcpyDeviceToDevice, h->stream));
+            HIPCHK(h, hipMemcpyAsync(nxt + (H - n) * ss, xb, n * ss, hipMemcpyDeviceToDevice, h->stream));
+        }
+        h->hist_sel ^= 1;
+    }
+    h->in_count = A + n;
+    h->out_count = m_end;
+    if (g.ne == 0)
+        h->keep_ctr -= nout;
+    else {
+        const long long last = g.keep_c0 + (g.ne - 1) * c.keep_n;
+        h->keep_ctr = c.keep_n - (nout - 1 - last);
+    }
+    return finish_out(h, out, n, g.ne);
 }
 
 // Run another decoder over the sliced bytes of the last batch (every row decoded

@@ -38,6 +38,9 @@
 
 struct PfbParams {
     const float2* x;        // capture 0, sample 0
+    const float2* hist;     // streaming: hist_len samples that precede x[0]; nullptr = zeros (stream start)
+    int hist_len;
+    long long in0;          // input index (relative to x[0]) of output 0's newest sample; 0 for whole captures
     long long stride;       // samples between captures
     long long n;            // samples per capture
     long long nout;         // outputs per channel (n / 64)
@@ -80,11 +83,13 @@ __global__ void __launch_bounds__(256) k_pfb(PfbParams Q)
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: guards on it are scalar branches
     const long long m0 = (long long)tile * PFB_TILE;
     const float2* __restrict__ x = Q.x + (long long)cap * Q.stride;
-    const long long lo_idx = (m0 - (P - 1)) * PFB_M - (PFB_M - 1);
+    const long long lo_idx = Q.in0 + (m0 - (P - 1)) * PFB_M - (PFB_M - 1);
     constexpr int count = (P + PFB_TILE - 1) * PFB_M;
 
     auto fetch = [&](long long idx) -> float2 {
-        return (idx >= 0 && idx < Q.n) ? x[idx] : make_float2(0.f, 0.f);
+        if (idx >= 0) return idx < Q.n ? x[idx] : make_float2(0.f, 0.f);
+        if (Q.hist && idx >= -(long long)Q.hist_len) return Q.hist[Q.hist_len + idx];
+        return make_float2(0.f, 0.f);
     };
 
     // ---- stage the tile (same scheme as k_frontend) -------------------------------
@@ -283,8 +288,8 @@ __global__ void __launch_bounds__(256) k_pfb(PfbParams Q)
         Q.tsum[row * Q.tiles_per_row + tile] = t;
     }
     int8_t* brow = Q.bits + row * Q.bits_stride;
-    if (Q.keep_n == 1) {   // keep_c0 == 0: the wave's 16 bytes are one aligned 16-B store
-        if (o_w + PFB_TM <= Q.nout) {
+    if (Q.keep_n == 1) {   // keep_c0 == 0: the wave's 16 bytes are one 16-B store when the row position allows
+        if (o_w + PFB_TM <= Q.nout && ((reinterpret_cast<uintptr_t>(brow + o_w) & 15) == 0)) {
             uint4 pk;
             unsigned* pw = reinterpret_cast<unsigned*>(&pk);
 #pragma unroll

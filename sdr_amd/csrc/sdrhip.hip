@@ -71,7 +71,8 @@ struct sdr_handle {
     long long runs_cap = 0;
     double* d_cur = nullptr;
     DecState* d_st = nullptr;
-    RuleState* d_rule = nullptr;    // callback-rule decoders: state between streaming calls
+    RuleState* d_rule = nullptr;    // callback-rule decoders: state between streaming calls (one per streaming row)
+    size_t rule_rows = 1;
     sdr_frame* d_frames = nullptr;
 
     // streaming state tracked on the host (pure functions of the sample counts)
@@ -410,6 +411,7 @@ static bool pick_win(const sdr_handle* h, long long nout, int& T, size_t& lds)
     if (h->front_mode == 1 || h->front_mode == 2 || h->rt_complex || h->in_fmt != SDR_IN_FC32 || h->cfg.decim != 1) return false;
     if (h->front_mode == 0 && h->ntaps < 8) return false;
     T = nout >= 8LL * 256 * WIN_R ? 256 : 64;
+    if (h->tile_override == 64 || h->tile_override == 128 || h->tile_override == 256) T = h->tile_override;
     lds = (size_t)win_tap_floats(h->ntaps) * 4 + (size_t)win_sample_slots(T, h->ntaps) * sizeof(float2);
     return lds <= 60 * 1024;
 }
@@ -445,8 +447,11 @@ static int reset_dec_state(sdr_handle* h)
     s0.first_evt = -1;
     s0.pulse_short_limit = 775.0;
     s0.gap_short_limit = 775.0;
-    HIPCHK(h, hipMemcpy(h->d_st, &s0, sizeof s0, hipMemcpyHostToDevice));
-    HIPCHK(h, hipMemset(h->d_rule, 0, sizeof(RuleState)));
+    // a plain chain streams through row 0 only; a channelizer through its 64 channel rows
+    const size_t rows = h->pfb_M ? (size_t)h->cfg.max_batch : 1;
+    std::vector<DecState> all(rows, s0);
+    HIPCHK(h, hipMemcpy(h->d_st, all.data(), rows * sizeof s0, hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemset(h->d_rule, 0, h->rule_rows * sizeof(RuleState)));
     h->carry_next = h->cfg.thr_init;
     h->carry_last = -1;
     return SDR_OK;
@@ -569,7 +574,8 @@ extern "C" int sdr_create(const sdr_chain_cfg* cfg, sdr_handle** out)
         HIPCHK(h, dev_alloc((void**)&h->d_cur, (size_t)(B * SDR_CUR_CAP) * sizeof(double)));
         HIPCHK(h, dev_alloc((void**)&h->d_st, (size_t)B * sizeof(DecState)));
         HIPCHK(h, hipMemset(h->d_st, 0, (size_t)B * sizeof(DecState)));
-        HIPCHK(h, dev_alloc((void**)&h->d_rule, sizeof(RuleState)));
+        h->rule_rows = (B == 64) ? 64 : 1;   // 64: a one-capture channelizer handle may stream (sdr_pfb_create)
+        HIPCHK(h, dev_alloc((void**)&h->d_rule, h->rule_rows * sizeof(RuleState)));
         {
             int r2 = reset_dec_state(h);
             if (r2) return r2;
@@ -771,6 +777,7 @@ struct CallGeom {
 
 static void fill_geom_gated(const sdr_handle* h, long long nitems, long long keep_c0, CallGeom& g);
 static int pfb_batch(sdr_handle* h, const void* iq, size_t n, size_t stride, int ncap, int is_dev, sdr_out* out);
+static int pfb_stream(sdr_handle* h, const void* iq, size_t n, int is_dev, sdr_out* out);
 static int launch_back(sdr_handle* h, int ncap, const CallGeom& g, long long patch_off, long long nb_total, int fresh,
                        int use_state_thr, int run_decoder);
 
@@ -1006,7 +1013,7 @@ static int launch_back(sdr_handle* h, int ncap, const CallGeom& g, long long pat
     Bp.pow_m13 = h->d_pow;
     Bp.log2n = h->d_log2;
     Bp.runs_n = h->d_runs_n;
-    Bp.rule = (!fresh && ncap == 1 && !is_stream_decoder(c.decoder) && c.decoder != SDR_DEC_NONE) ? h->d_rule : nullptr;
+    Bp.rule = (!fresh && (size_t)ncap <= h->rule_rows && !is_stream_decoder(c.decoder) && c.decoder != SDR_DEC_NONE) ? h->d_rule : nullptr;
     const bool full_pass = run_decoder && c.decoder != SDR_DEC_NONE && !Bp.nout_var;
     if (h->reuse_next && h->runs_valid && full_pass && !h->no_reuse) {
         Bp.reuse_runs = 1;
@@ -1226,7 +1233,7 @@ static int stream_decode_step(sdr_handle* h, const CallGeom& g, const float2* x,
 extern "C" int sdr_process_iq(sdr_handle* h, const void* iq, size_t n, int is_dev, sdr_out* out)
 {
     if (!h || (!iq && n)) return fail(h, SDR_E_ARG, "sdr_process_iq: bad argument");
-    if (h->pfb_M) return fail(h, SDR_E_ARG, "sdr_process_iq: a channelizer handle takes whole captures (sdr_batch_process)");
+    if (h->pfb_M) return pfb_stream(h, iq, n, is_dev, out);
     if (h->pre) {
         int r = sdr_process_iq(h->pre, iq, n, is_dev, nullptr);
         if (r) return fail(h, r, "prefilter: " + h->pre->err);
@@ -1341,6 +1348,16 @@ __global__ void k_pack_rows(const unsigned char* __restrict__ src, size_t spitch
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const size_t r = i / width, c = i - r * width;
         dst[i] = src[r * spitch + c];
+    }
+}
+
+__global__ void k_copy_rows(const unsigned char* __restrict__ src, size_t spitch, unsigned char* __restrict__ dst,
+                            size_t dpitch, size_t width, size_t rows)
+{
+    const size_t total = width * rows;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = i / width, c = i - r * width;
+        dst[r * dpitch + c] = src[r * spitch + c];
     }
 }
 
@@ -1521,7 +1538,7 @@ extern "C" int sdr_history_len(sdr_handle* h) { return h ? h->hist_len : SDR_E_A
 extern "C" int sdr_seek(sdr_handle* h, uint64_t abs_index, const void* halo, size_t n_halo, int is_dev)
 {
     if (!h) return fail(h, SDR_E_ARG, "sdr_seek: null handle");
-    if (h->pre || h->squelch_on || h->cfg.post_ntaps > 0 || h->prerotate || h->pfb_M)
+    if (h->pre || h->squelch_on || h->cfg.post_ntaps > 0 || h->prerotate)
         return fail(h, SDR_E_ARG, "sdr_seek: chains with a prefilter, squelch or post-demod filter cannot be positioned from a halo");
     const size_t H = (size_t)h->hist_len;
     const size_t need = abs_index < H ? (size_t)abs_index : H;
@@ -1567,6 +1584,80 @@ extern "C" int sdr_segment_info_get(sdr_handle* h, sdr_segment_info* info)
     info->carry_in = h->carry_last;
     if (h->carry_next < 0) h->carry_next = s.thr_state;
     return SDR_OK;
+}
+
+extern "C" int sdr_segment_info_rows(sdr_handle* h, sdr_segment_info* info, size_t cap, size_t* n)
+{
+    if (!h || !n) return fail(h, SDR_E_ARG, "sdr_segment_info_rows: null argument");
+    (void)hipSetDevice(h->device);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const size_t rows = (size_t)h->last_ncap;
+    *n = rows;
+    if (!info || cap < rows || rows == 0) return SDR_OK;
+    std::vector<DecState> st(rows);
+    HIPCHK(h, hipMemcpy(st.data(), h->d_st, rows * sizeof(DecState), hipMemcpyDeviceToHost));
+    const long long kn = h->cfg.keep_n, nb = h->last_nb, c0 = h->last_keep_c0;
+    for (size_t r = 0; r < rows; ++r) {
+        sdr_segment_info& o = info[r];
+        memset(&o, 0, sizeof o);
+        o.n_bits = (uint64_t)nb;
+        o.first_bit_index = (uint64_t)((h->last_out0 + (unsigned long long)c0 + 1ull) / (unsigned long long)kn) - 1ull;
+        long long und = nb;
+        if (st[r].first_evt >= 0) {
+            und = st[r].first_evt <= c0 ? 0 : ((long long)st[r].first_evt - c0 + kn - 1) / kn;
+            if (und > nb) und = nb;
+        }
+        o.n_undetermined = (uint64_t)und;
+        o.has_event = st[r].first_evt >= 0;
+        o.last_state = st[r].thr_state;
+        o.carry_in = h->carry_last;
+    }
+    return SDR_OK;
+}
+
+// Decoder-only batch entry: `rows` independent sliced streams of n bytes (row r at bits + r*stride), each
+// decoded from a fresh decoder object as ONE work() call -- sdr_batch_process without the front end.
+extern "C" int sdr_batch_process_bits(sdr_handle* h, const int8_t* bits, size_t n, size_t stride, int rows, int is_dev,
+                                      sdr_out* out)
+{
+    if (!h || !bits || rows < 1) return fail(h, SDR_E_ARG, "sdr_batch_process_bits: bad argument");
+    if (h->cfg.decoder == SDR_DEC_NONE) return fail(h, SDR_E_ARG, "sdr_batch_process_bits: no decoder configured");
+    if (rows > h->cfg.max_batch || (long long)n > h->bits_stride)
+        return fail(h, SDR_E_CAPACITY, "sdr_batch_process_bits: more rows or longer rows than the handle was created for");
+    if (stride < n) return fail(h, SDR_E_ARG, "sdr_batch_process_bits: stride < n");
+    (void)hipSetDevice(h->device);
+    if (n) {
+        if (rows == 1 || (stride == n && (size_t)h->bits_stride == n))
+            HIPCHK(h, hipMemcpyAsync(h->d_bits, bits, n * (size_t)rows, is_dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
+                                     h->stream));
+        else if (is_dev) {
+            size_t total = n * (size_t)rows, blocks = (total + 255) / 256;
+            if (blocks > 4096) blocks = 4096;
+            hipLaunchKernelGGL(k_copy_rows, dim3((unsigned)blocks), dim3(256), 0, h->stream, (const unsigned char*)bits, stride,
+                               (unsigned char*)h->d_bits, (size_t)h->bits_stride, n, (size_t)rows);
+            HIPCHK(h, hipGetLastError());
+        } else
+            for (int r = 0; r < rows; ++r)
+                HIPCHK(h, hipMemcpyAsync(h->d_bits + (size_t)r * h->bits_stride, bits + (size_t)r * stride, n,
+                                         hipMemcpyHostToDevice, h->stream));
+    }
+    CallGeom g;
+    memset(&g, 0, sizeof g);
+    g.ne = (long long)n;
+    g.T = 256;
+    g.tile_out = 256;
+    int run = 1;
+    if (is_stream_decoder(h->cfg.decoder))
+        run = ((double)g.ne * 1e6 / h->dec_rate > decoder_reset_limit(h->cfg.decoder)) ? 1 : 0;
+    if (h->profile) HIPCHK(h, hipEventRecord(h->pev[3 * (h->pcount % SDR_PROF_RING)], h->stream));
+    int r = launch_back(h, rows, g, 0, g.ne, 1, 0, run);
+    if (r) return r;
+    h->last_ncap = rows;
+    h->last_nb = g.ne;
+    h->last_nout = 0;
+    h->last_bits_off = 0;
+    h->raw_n = 0;
+    return finish_out(h, out, 0, g.ne);
 }
 
 extern "C" int sdr_export_bits(sdr_handle* h, void* bits_dev, size_t cap_bytes, size_t* n)

@@ -96,6 +96,62 @@ def gather_stream(bits, n_bits, n_undetermined, has_event, last_state, world, th
     return torch.cat(parts), offsets
 
 
+def stitch_rows(bits_list, infos_list, thr_init=0):
+    """Single-process form for a multi-row handle (channelizer: 64 channel rows per segment).
+    bits_list[s]: (rows, n_s) array of segment s; infos_list[s]: its per-row SegmentInfo list.
+    -> (rows, total) int8: every row's stream over the whole capture."""
+    rows = len(infos_list[0])
+    out = []
+    for r in range(rows):
+        carries = resolve_carries([inf[r].has_event for inf in infos_list], [inf[r].last_state for inf in infos_list], thr_init)
+        parts = []
+        for b, inf, c in zip(bits_list, infos_list, carries):
+            row = np.array(np.asarray(b)[r], np.int8, copy=True)
+            parts.append(patch(row, inf[r].n_undetermined, c, thr_init))
+        out.append(np.concatenate(parts))
+    return np.stack(out)
+
+
+def gather_rows(bits, n_bits, n_undetermined, has_event, last_state, world, thr_init=0):
+    """Collective form for a multi-row handle, one rank per segment (rank order == segment order).
+    bits: (rows, >= n_bits) uint8/int8 torch tensor on this rank's device, computed with carry-in `thr_init`;
+    n_undetermined / has_event / last_state: one value per row (sdr_segment_info_rows).
+    Two all_gathers: 3 int64 per row + the segment length, then the padded rows.
+    Returns (stream[rows, total], offsets) on every rank."""
+    import torch
+    import torch.distributed as dist
+    dev = bits.device
+    rows = int(bits.shape[0])
+    mine = torch.zeros(3 * rows + 1, dtype=torch.int64, device=dev)
+    mine[0] = int(n_bits)
+    mine[1:1 + rows] = torch.as_tensor([int(v) for v in n_undetermined], dtype=torch.int64)
+    mine[1 + rows:1 + 2 * rows] = torch.as_tensor([int(v) for v in has_event], dtype=torch.int64)
+    mine[1 + 2 * rows:] = torch.as_tensor([int(v) for v in last_state], dtype=torch.int64)
+    allv = torch.zeros(world * mine.numel(), dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(allv, mine)
+    tab = allv.view(world, -1).cpu().numpy()
+    nb = tab[:, 0]
+    und, he, ls = tab[:, 1:1 + rows], tab[:, 1 + rows:1 + 2 * rows], tab[:, 1 + 2 * rows:]
+    rank = dist.get_rank()
+    for r in range(rows):
+        carries = resolve_carries(he[:, r], ls[:, r], thr_init)
+        patch(bits[r], und[rank, r], carries[rank], thr_init)
+    width = int(nb.max()) if world else 0
+    width = max(16, -(-width // 16) * 16)
+    send = torch.zeros((rows, width), dtype=bits.dtype, device=dev)
+    send[:, :int(n_bits)] = bits[:, :int(n_bits)]
+    recv = torch.zeros(world * rows * width, dtype=bits.dtype, device=dev)
+    dist.all_gather_into_tensor(recv, send.reshape(-1))
+    recv = recv.view(world, rows, width)
+    parts, offsets, off = [], [], 0
+    for w in range(world):
+        k = int(nb[w])
+        parts.append(recv[w, :, :k])
+        offsets.append(off)
+        off += k
+    return torch.cat(parts, dim=1), offsets
+
+
 def run_segment(chain, iq, start, end):
     """Front end of ONE segment of a capture that this process can index as
     `iq[a:b]` (numpy array or torch tensor on the GPU): seek with the halo, one

@@ -98,9 +98,10 @@ def test_pfb_argument_checks():
         chain.Chain(FS, channels=32, max_samples=4096)
     with pytest.raises(_lib.SdrError):
         chain.Chain(FS, channels=64, demod=chain.DEMOD_QUAD, max_samples=4096)
-    with chain.Chain(FS, channels=64, taps=_proto(), max_samples=4096) as c:
-        with pytest.raises(_lib.SdrError):
+    with chain.Chain(FS, channels=64, taps=_proto(), max_samples=4096, max_batch=2) as c:
+        with pytest.raises(_lib.SdrError):       # only a one-capture channelizer streams
             c.process_iq(np.zeros(64, np.complex64))
+    with chain.Chain(FS, channels=64, taps=_proto(), max_samples=4096) as c:
         with pytest.raises(_lib.SdrError):
             c.set_taps(np.ones(1025, np.float32))
         out = c.batch_process(np.zeros((1, 63), np.complex64))   # fewer samples than one output
