@@ -353,7 +353,12 @@ SDR_API int sdr_redecode(sdr_handle* h, int decoder, double decoder_rate);
  * (taps 1, center_freq -shift) -> rational_resampler_ccc 1/int(samp_rate/500e3)
  * -> low_pass_filter (Blackman) -> analog_wfm_rcv (quadrature_demod ->
  * fir_filter_fff audio_decimation -> fm_deemph 75 us) -> rational_resampler_fff
- * 48/50 -> multiply_const(volume).  One call = one capture from stream start. */
+ * 48/50 -> multiply_const(volume).  The flowgraph is a live stream: sdr_fm_process takes the next
+ * chunk (any length), every block's state persists between calls (channel-filter histories and
+ * rotator phase, the discriminator's previous sample, the audio FIR's history and decimation
+ * phase, the de-emphasis delay line in double precision, the resampler's history and output
+ * phase), so any chunking of a stream gives the same audio as one call; the first call after
+ * sdr_fm_create / sdr_fm_reset starts at stream start. */
 typedef struct sdr_fm_cfg {
     double sample_rate;      /* samp_rate of the IQ stream */
     double center_freq;      /* freq_xlating center_freq (= -shift in the GRC) */
@@ -373,9 +378,10 @@ typedef struct sdr_fm sdr_fm;
 SDR_API int sdr_fm_create(const sdr_fm_cfg* cfg, sdr_fm** out);
 SDR_API int sdr_fm_destroy(sdr_fm* h);
 SDR_API int sdr_fm_set_stream(sdr_fm* h, void* hip_stream);
+SDR_API int sdr_fm_reset(sdr_fm* h);
 /* iq: n complex64 samples (host or device); n_audio receives the audio sample count. */
 SDR_API int sdr_fm_process(sdr_fm* h, const void* iq, size_t n, int is_device_ptr, size_t* n_audio);
-/* stage outputs of the last call: 0 resampled complex (pairs), 1 discriminator,
+/* stage outputs of the last call (this call's new items only): 0 resampled complex (pairs), 1 discriminator,
  * 2 audio FIR, 3 de-emphasis, 4 final audio.  out may be NULL to query *n (floats). */
 SDR_API int sdr_fm_fetch(sdr_fm* h, int stage, float* out, size_t cap, size_t* n);
 SDR_API const char* sdr_fm_last_error(sdr_fm* h);

@@ -16,7 +16,25 @@ struct sdr_fm {
     double b0 = 0, p1 = 0;
     float *d_a2 = nullptr, *d_a3 = nullptr, *d_audio = nullptr;
     long long n1 = 0, n2 = 0, n4 = 0, cap2 = 0, cap4 = 0;
+    // streaming state of the back half (the chain handles A and B carry their own)
+    float* d_chist[2] = {nullptr, nullptr};   // audio FIR: the last n_ataps-1+2D discriminator floats
+    float* d_ehist[2] = {nullptr, nullptr};   // audio resampler: the last taps-per-phase de-emphasised floats
+    int chist_len = 0, ehist_len = 0, csel = 0, esel = 0, dsel = 0;
+    unsigned long long c_in = 0, c_out = 0;   // discriminator floats consumed / audio-FIR outputs emitted
+    unsigned long long e_in = 0, e_out = 0;   // de-emphasised floats consumed / audio samples emitted
+    FmDeemphState* d_deemph = nullptr;        // two slots, read dsel / write dsel^1
 };
+
+// last H floats of (hist ++ x[0..n)) -> the other history buffer
+static int fm_hist_update(sdr_fm* h, float** bufs, int& sel, int H, const float* x, long long n);
+static int chain_restart(sdr_handle* c)
+{
+    (void)hipSetDevice(c->device);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int i = 0; i < 2; ++i) HIPCHK(c, hipMemset(c->d_hist[i], 0, (size_t)c->hist_cap * sizeof(float2)));
+    reset_stream_counters(c);
+    return reset_dec_state(c);
+}
 
 static int fm_fail(sdr_fm* h, int code, const std::string& msg)
 {
@@ -39,7 +57,8 @@ extern "C" int sdr_fm_destroy(sdr_fm* h)
     if (!h) return SDR_OK;
     if (h->A) sdr_destroy(h->A);
     if (h->B) sdr_destroy(h->B);
-    void* ptrs[] = {h->d_ataps, h->d_rtaps, h->d_a2, h->d_a3, h->d_audio};
+    void* ptrs[] = {h->d_ataps, h->d_rtaps, h->d_a2, h->d_a3, h->d_audio, h->d_chist[0], h->d_chist[1], h->d_ehist[0],
+                    h->d_ehist[1], h->d_deemph};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     delete h;
@@ -146,6 +165,16 @@ extern "C" int sdr_fm_create(const sdr_fm_cfg* cfg, sdr_fm** out)
         FMCHK(h, dev_alloc((void**)&h->d_a2, (size_t)h->cap2 * sizeof(float)));
         FMCHK(h, dev_alloc((void**)&h->d_a3, (size_t)h->cap2 * sizeof(float)));
         FMCHK(h, dev_alloc((void**)&h->d_audio, (size_t)h->cap4 * sizeof(float)));
+        h->chist_len = h->n_ataps - 1 + 2 * cfg->audio_decim;
+        h->ehist_len = (h->n_rtaps + h->L - 1) / h->L;
+        for (int i = 0; i < 2; ++i) {
+            FMCHK(h, dev_alloc((void**)&h->d_chist[i], (size_t)h->chist_len * sizeof(float)));
+            FMCHK(h, dev_alloc((void**)&h->d_ehist[i], (size_t)h->ehist_len * sizeof(float)));
+            FMCHK(h, hipMemset(h->d_chist[i], 0, (size_t)h->chist_len * sizeof(float)));
+            FMCHK(h, hipMemset(h->d_ehist[i], 0, (size_t)h->ehist_len * sizeof(float)));
+        }
+        FMCHK(h, dev_alloc((void**)&h->d_deemph, 2 * sizeof(FmDeemphState)));
+        FMCHK(h, hipMemset(h->d_deemph, 0, 2 * sizeof(FmDeemphState)));
         h->stream = h->A->own_stream;
         sdr_set_stream(h->B, (void*)h->stream);
         return SDR_OK;
@@ -170,46 +199,112 @@ extern "C" int sdr_fm_set_stream(sdr_fm* h, void* s)
     return SDR_OK;
 }
 
+static int fm_hist_update(sdr_fm* h, float** bufs, int& sel, int H, const float* x, long long n)
+{
+    if (n <= 0 || H <= 0) return SDR_OK;
+    float* cur = bufs[sel];
+    float* nxt = bufs[sel ^ 1];
+    if (n >= H)
+        FMCHK(h, hipMemcpyAsync(nxt, x + (n - H), (size_t)H * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+    else {
+        FMCHK(h, hipMemcpyAsync(nxt, cur + n, (size_t)(H - n) * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+        FMCHK(h, hipMemcpyAsync(nxt + (H - n), x, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+    }
+    sel ^= 1;
+    return SDR_OK;
+}
+
+// back to stream start (as after sdr_fm_create)
+extern "C" int sdr_fm_reset(sdr_fm* h)
+{
+    if (!h) return SDR_E_ARG;
+    FMCHK(h, hipStreamSynchronize(h->stream));
+    int rc = chain_restart(h->A);
+    if (rc) return fm_fail(h, rc, h->A->err);
+    rc = chain_restart(h->B);
+    if (rc) return fm_fail(h, rc, h->B->err);
+    for (int i = 0; i < 2; ++i) {
+        FMCHK(h, hipMemset(h->d_chist[i], 0, (size_t)h->chist_len * sizeof(float)));
+        FMCHK(h, hipMemset(h->d_ehist[i], 0, (size_t)h->ehist_len * sizeof(float)));
+    }
+    FMCHK(h, hipMemset(h->d_deemph, 0, 2 * sizeof(FmDeemphState)));
+    h->c_in = h->c_out = h->e_in = h->e_out = 0;
+    h->csel = h->esel = h->dsel = 0;
+    h->n1 = h->n2 = h->n4 = 0;
+    return SDR_OK;
+}
+
+// One scheduler pass of the flowgraph over n more input samples.  Every block's state persists: the two
+// channel-filter stages in their chain handles (FIR history, input-rotator phase, discriminator's previous
+// sample), the audio FIR's history and decimation phase, the de-emphasis delay line (exact, double), the
+// audio resampler's history and output phase.  The first call after create / sdr_fm_reset is the capture from
+// stream start; any chunking of a stream yields the same audio.
 extern "C" int sdr_fm_process(sdr_fm* h, const void* iq, size_t n, int is_dev, size_t* n_audio)
 {
-    if (!h || !iq) return fm_fail(h, SDR_E_ARG, "sdr_fm_process: bad argument");
-    if (n > h->cfg.max_samples) return fm_fail(h, SDR_E_CAPACITY, "sdr_fm_process: capture larger than max_samples");
-    int rc = sdr_batch_process(h->A, iq, n, n, 1, is_dev, nullptr);
+    if (!h || (!iq && n)) return fm_fail(h, SDR_E_ARG, "sdr_fm_process: bad argument");
+    if (n > h->cfg.max_samples) return fm_fail(h, SDR_E_CAPACITY, "sdr_fm_process: chunk larger than max_samples");
+    h->n1 = h->n2 = h->n4 = 0;
+    if (n_audio) *n_audio = 0;
+    int rc = sdr_process_iq(h->A, iq, n, is_dev, nullptr);
     if (rc) return fm_fail(h, rc, std::string("stage A: ") + h->A->err);
     h->n1 = h->A->last_nout;
-    h->n2 = h->n1 / h->cfg.audio_decim;
-    h->n4 = (h->n2 * h->L + h->M - 1) / h->M;
-    if (n_audio) *n_audio = (size_t)h->n4;
     if (h->n1 == 0) return SDR_OK;
-    rc = sdr_batch_process(h->B, h->A->d_tap, (size_t)h->n1, (size_t)h->n1, 1, 1, nullptr);
+    rc = sdr_process_iq(h->B, h->A->d_tap, (size_t)h->n1, 1, nullptr);
     if (rc) return fm_fail(h, rc, std::string("stage B: ") + h->B->err);
-    if (h->n2 == 0) return SDR_OK;
-    {
-        const int T = 256, D = h->cfg.audio_decim;
+    // audio FIR: outputs are emitted once audio_decim discriminator floats are consumed
+    const int D = h->cfg.audio_decim;
+    const unsigned long long c_end = (h->c_in + (unsigned long long)h->n1) / (unsigned long long)D;
+    h->n2 = (long long)(c_end - h->c_out);
+    if (h->n2 > h->cap2) return fm_fail(h, SDR_E_CAPACITY, "sdr_fm_process: audio buffer too small");
+    if (h->n2 > 0) {
+        const int T = 256;
         size_t lds = ((size_t)(T - 1) * D + h->n_ataps) * sizeof(float);
         int blocks = (int)((h->n2 + T - 1) / T);
-        hipLaunchKernelGGL(k_fir_fff_decim, dim3(blocks), dim3(T), lds, h->stream, h->B->d_tap, h->n1, h->n2,
-                           h->d_ataps, h->n_ataps, D, h->d_a2);
+        const long long in0 = (long long)(h->c_out * (unsigned long long)D) - (long long)h->c_in;
+        const int hv = h->c_in < (unsigned long long)h->chist_len ? (int)h->c_in : h->chist_len;
+        hipLaunchKernelGGL(k_fir_fff_decim, dim3(blocks), dim3(T), lds, h->stream, h->B->d_tap,
+                           h->d_chist[h->csel] + (h->chist_len - hv), hv, h->n1, in0, h->n2, h->d_ataps, h->n_ataps, D,
+                           h->d_a2);
         FMCHK(h, hipGetLastError());
     }
+    rc = fm_hist_update(h, h->d_chist, h->csel, h->chist_len, h->B->d_tap, h->n1);
+    if (rc) return rc;
+    h->c_in += (unsigned long long)h->n1;
+    h->c_out = c_end;
+    if (h->n2 == 0) return SDR_OK;
     {
         // warm-up length after which p1^k < 2^-60; fall back to the scan kernel for poles near 1
         int warm = (h->p1 > 0.0 && h->p1 < 1.0) ? (int)ceil(-60.0 * log(2.0) / log(h->p1)) : 1 << 30;
+        const FmDeemphState* st_in = h->d_deemph + h->dsel;
+        FmDeemphState* st_out = h->d_deemph + (h->dsel ^ 1);
         if (warm <= 2048) {
             long long chunks = (h->n2 + DEEMPH_CHUNK - 1) / DEEMPH_CHUNK;
             hipLaunchKernelGGL(k_deemph_warm, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, h->stream, h->d_a2,
-                               h->n2, h->b0, h->p1, warm, h->d_a3);
+                               h->n2, h->b0, h->p1, warm, h->d_a3, st_in, st_out);
         } else
             hipLaunchKernelGGL(k_deemph, dim3(1), dim3(DEEMPH_THREADS), 0, h->stream, h->d_a2, h->n2, h->b0, h->p1,
-                               h->d_a3);
+                               h->d_a3, st_in, st_out);
         FMCHK(h, hipGetLastError());
+        h->dsel ^= 1;
     }
-    {
+    // audio resampler: output m exists once input floor(m*M/L) does
+    const unsigned long long e_in_end = h->e_in + (unsigned long long)h->n2;
+    const unsigned long long e_end = (e_in_end * (unsigned long long)h->L + (unsigned long long)h->M - 1ull) / (unsigned long long)h->M;
+    h->n4 = (long long)(e_end - h->e_out);
+    if (h->n4 > h->cap4) return fm_fail(h, SDR_E_CAPACITY, "sdr_fm_process: audio buffer too small");
+    if (h->n4 > 0) {
         int blocks = (int)((h->n4 + 255) / 256);
-        hipLaunchKernelGGL(k_resample_fff, dim3(blocks), dim3(256), 0, h->stream, h->d_a3, h->n2, h->n4, h->d_rtaps,
-                           h->n_rtaps, h->L, h->M, h->cfg.volume, h->d_audio);
+        const int hv = h->e_in < (unsigned long long)h->ehist_len ? (int)h->e_in : h->ehist_len;
+        hipLaunchKernelGGL(k_resample_fff, dim3(blocks), dim3(256), 0, h->stream, h->d_a3,
+                           h->d_ehist[h->esel] + (h->ehist_len - hv), hv, h->n2, (long long)h->e_in, (long long)h->e_out,
+                           h->n4, h->d_rtaps, h->n_rtaps, h->L, h->M, h->cfg.volume, h->d_audio);
         FMCHK(h, hipGetLastError());
     }
+    rc = fm_hist_update(h, h->d_ehist, h->esel, h->ehist_len, h->d_a3, h->n2);
+    if (rc) return rc;
+    h->e_in = e_in_end;
+    h->e_out = e_end;
+    if (n_audio) *n_audio = (size_t)h->n4;
     return SDR_OK;
 }
 

@@ -54,8 +54,14 @@ class FmRadio(object):
     def set_stream(self, ptr):
         self._check(self._L.sdr_fm_set_stream(self._h, C.c_void_p(ptr)))
 
+    def reset(self):
+        """Back to stream start (every block's state as after construction)."""
+        self._check(self._L.sdr_fm_reset(self._h))
+
     def process(self, iq):
-        """One capture from stream start; returns the audio sample count."""
+        """One scheduler pass over the next chunk of the stream (all block state persists between calls; the
+        first call after construction / reset() is the capture from stream start); returns the audio sample
+        count of this call."""
         if type(iq).__module__.startswith("torch") and iq.is_cuda:
             n = iq.numel() if iq.is_complex() else iq.numel() // 2
             ptr, dev, self._keep = iq.data_ptr(), 1, iq

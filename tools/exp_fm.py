@@ -7,7 +7,7 @@ iq = synth.fm_iq(n, 2.4e6, seed=98)
 x = torch.from_numpy(iq.view(np.float32)).cuda()
 r = fm.FmRadio(samp_rate=2.4e6, max_samples=n)
 r.set_stream(torch.cuda.current_stream().cuda_stream)
-for _ in range(3): r.process(x)
+for _ in range(3): r.process(x)  # streaming object: a continuous stream of repeats
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 K = 20
