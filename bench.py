@@ -185,16 +185,18 @@ def fm_workload(torch, dev, skip_cpu, n=1 << 26, fs=2.4e6, steps=10):
     x1 = torch.from_numpy(iq.view(np.float32)).to(dev)
     x = x1.repeat(n // m, 1) if x1.dim() == 2 else x1.repeat(n // m)
     r = fm.FmRadio(samp_rate=fs, shift=200e3, max_samples=n)
-    r.set_stream(torch.cuda.current_stream().cuda_stream)
+    st = torch.cuda.Stream(device=dev)            # a real stream handle (the default stream's is 0 = "the chain's own")
+    r.set_stream(st.cuda_stream)
+    torch.cuda.synchronize()
     for _ in range(2):
         na = r.process(x)
     torch.cuda.synchronize()
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     t0 = time.perf_counter()
-    ev[0].record()
+    ev[0].record(st)
     for k in range(steps):
         r.process(x)
-        ev[k + 1].record()
+        ev[k + 1].record(st)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     gpu_ms = float(np.mean([ev[k].elapsed_time(ev[k + 1]) for k in range(steps)]))
@@ -266,12 +268,13 @@ def r_shape_workload(torch, dev, skip_cpu, ncap=64, n=1 << 19, fs=2e6, steps=20)
     out = {"value": round(ncap * n / dt / 1e6, 1), "unit": "Msps", "ms_per_step": round(dt * 1e3, 4),
            "captures": ncap, "samples_per_capture": n, "sample_rate": fs, "ntaps": int(taps.size), "decim": 1,
            "keep_n": 100, "chain": "fir_filter_ccf->mag2->threshold->slicer->keep_one_in_n->ts33c_decoder",
-           "roofline": {"bound": "mfma", "kernel": "k_frontend_mfma", "achieved": round(flops / (fk * 1e-3) / 1e12, 1),
+           "roofline": {"bound": "mfma", "kernel": "k_frontend_win", "achieved": round(flops / (fk * 1e-3) / 1e12, 1),
                         "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(flops / (fk * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4), "traffic": None,
                         "kernel_ms": round(fk, 4), "backend_kernel_ms": round(float(np.mean(back_ms)), 4),
-                        "flops_per_launch": flops, "note": "algorithmic flops = 4*ntaps per input sample (real taps); "
-                        "the banded-Toeplitz MFMA form issues (15+ntaps)/ntaps times that"},
+                        "flops_per_launch": flops, "note": "algorithmic flops = 4*ntaps per input sample (real taps); peak = the f32 "
+                        "FMA rate (packed VALU = f32-input MFMA, 157.3 TF); the sliding-window VALU kernel issues exactly "
+                        "the algorithmic fmas (the banded-Toeplitz MFMA form, SDR_FRONTEND=mfma, (15+ntaps)/ntaps times as many)"},
            "verified": "all captures decode to the transmitted packets"}
     if not skip_cpu:
         from oracle import decoders as odec
@@ -394,9 +397,12 @@ def tfa_fsk_workload(torch, dev, skip_cpu, ncap=64, n=1 << 20, fs=2e6, dev_hz=60
     out = {"value": round(ncap * n / dt / 1e6, 1), "unit": "Msps", "ms_per_step": round(dt * 1e3, 4), "captures": ncap,
            "samples_per_capture": n, "sample_rate": fs, "ntaps": int(taps.size), "decim": 1, "packets_per_capture": 18,
            "chain": "fir_filter_ccf->quadrature_demod->threshold->slicer->tfa_stream_decoder",
-           "roofline": {"bound": "hbm", "kernel": "front end (k_frontend*)", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "kernel_ms": round(fk, 4),
-                        "backend_kernel_ms": round(float(np.mean(back_ms)), 4), "bytes_per_launch": bps * ncap * n},
+           "roofline": {"bound": "hbm", "kernel": "k_frontend_win", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                        "traffic": pmc_traffic("k_frontend_win tfa", "captures=%d" % ncap)[0], "kernel_ms": round(fk, 4),
+                        "backend_kernel_ms": round(float(np.mean(back_ms)), 4), "bytes_per_launch": bps * ncap * n,
+                        "note": "27 taps at decimation 1 + one fast_atan2f per sample: 108 + ~90 flop-equivalents per 9 bytes, "
+                                "bound by VALU instruction issue (profiles/r02_a_win_sq.csv), not by HBM"},
            "verified": "all captures decode to the transmitted packets (CRC-8 ok)"}
     if not skip_cpu:
         from oracle import decoders as odec
@@ -661,11 +667,14 @@ def pfb_workload(torch, dev, skip_cpu, n=1 << 26, fs=20e6, steps=10):
     return out
 
 
+PMC_FILE = "r02_a_pmc.json"   # the committed FETCH_SIZE / WRITE_SIZE passes of the current kernels (tools/profile_round.sh)
+
+
 def pmc_traffic(kernel_key, workload_tag):
     """HBM bytes per launch of one kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
     WRITE_SIZE over this same command; counters cannot be read from inside the process).  None if the
     committed workload differs from the one being run."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_q_pmc.json")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", PMC_FILE)
     try:
         with open(path) as f:
             rec = json.load(f)["kernels"][kernel_key]
@@ -673,7 +682,7 @@ def pmc_traffic(kernel_key, workload_tag):
         return None, None
     if workload_tag not in rec.get("workload", ""):
         return None, None
-    return int(rec["hbm_bytes"]), "profiles/r01_q_pmc.json"
+    return int(rec["hbm_bytes"]), "profiles/" + PMC_FILE
 
 
 def launch_ranks(n, argv, rehearsal):

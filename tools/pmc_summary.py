@@ -19,7 +19,9 @@ def main(fetch_csv, write_csv, out_json):
     want = [("k_frontend<true, false>", "k_frontend<true, false> fc32", 8.02 * n, "ook_batch_ts33c_xlating captures_per_gpu=1250", "128"),
             ("k_frontend<true, false>", "k_frontend<true, false> fc32 D=10", 8.1 * n, "ook_batch_somfy_berner_mumbi captures=1250", "256"),
             ("k_frontend_raw8", "k_frontend_raw8 cu8", 2.02 * n, "ook_batch_cu8 captures_per_gpu=1250", None),
-            ("k_pfb<8>", "k_pfb<8>", (8 + 1 / 16) * (1 << 26), "wideband_pfb64 samples=2^26", None)]
+            ("k_pfb<8>", "k_pfb<8>", (8 + 1 / 16) * (1 << 26), "wideband_pfb64 samples=2^26", None),
+            # k_frontend_win also serves the R shape and the FM chain's second stage: the TFA batch is the largest
+            ("k_frontend_win", "k_frontend_win tfa", 9.0 * 64 * (1 << 20), "tfa_fsk_discriminator captures=64", None)]
     out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE --kernel-trace (separate passes), python3 bench.py "
                      "--steps 3 --warmup 1 --no-cpu-baseline; per-launch means",
            "correction": "gfx950: FETCH_SIZE counts the 128-B requests of 16-B/lane streaming reads at 64 B "
