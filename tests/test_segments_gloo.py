@@ -106,3 +106,71 @@ def test_resolve_carries_and_bounds():
         assert len(b) == w and b[0][0] == 0 and b[-1][1] == n
         for (a0, a1), (b0, b1) in zip(b, b[1:]):
             assert a1 == b0 and (a1 % al == 0 or a1 == n)
+
+
+# ---- configs[4]: the 64 channel rows of a wideband capture channelized in segments (segments.gather_rows)
+PFB_FS, PFB_M, PFB_KEEP, PFB_N = 20e6, 64, 4, 1 << 18
+
+
+def _pfb_mags():
+    """|y_c[m]|^2 of the oracle channelizer over the whole capture (every rank can afford it at this size); the
+    per-segment front end is modelled from it exactly as in _segment_model."""
+    rng = np.random.default_rng(5)
+    sym = []
+    for _ in range(6):
+        sym += [(1, float(rng.integers(300, 1500))), (0, float(rng.integers(300, 1500)))]
+    em = [(7 * PFB_FS / PFB_M, sym, 500.0), ((40 - 64) * PFB_FS / PFB_M, sym[::-1], 2000.0), (21 * PFB_FS / PFB_M, sym * 2, 100.0)]
+    x = synth.wideband_capture(PFB_N, PFB_FS, em, seed=6)
+    taps = odsp.low_pass(1.0, PFB_FS, 100e3, 100e3)
+    y = odsp.pfb_channelize(x, taps, PFB_M)
+    return np.stack([odsp.mag2(y[c]) for c in range(PFB_M)])
+
+
+def _pfb_worker(rank, world, port, lo, hi, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mags = _pfb_mags()
+    a, b = segments.segment_bounds(PFB_N, world, PFB_M * PFB_KEEP)[rank]
+    rows, und, he, ls = [], [], [], []
+    for c in range(PFB_M):
+        bits, u, h, l = _segment_model(mags[c], a // PFB_M, b // PFB_M, np.float32(lo), np.float32(hi), PFB_KEEP)
+        rows.append(bits)
+        und.append(u)
+        he.append(h)
+        ls.append(l)
+    bits = torch.from_numpy(np.stack(rows).copy())
+    stream, offs = segments.gather_rows(bits, bits.shape[1], und, he, ls, world, 0)
+    q.put((rank, stream.numpy().copy(), offs, int(sum(und))))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("lo,hi", [(0.05, 0.15), (1e-12, 0.05)])
+def test_channelizer_rows_stitch_world2(lo, hi):
+    """64 rows, world size 2: per-row carries resolved across the segment boundary; the second threshold pair
+    leaves idle channels between the thresholds, so their second segment starts undetermined"""
+    world = 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_pfb_worker, args=(r, world, port, lo, hi, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(world):
+        r, stream, offs, und = q.get(timeout=240)
+        got[r] = (stream, offs, und)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    mags = _pfb_mags()
+    want = np.stack([odsp.slice_bits(mags[c], 1.0, lo, hi, PFB_KEEP)[0] for c in range(PFB_M)])
+    for r in range(world):
+        assert got[r][0].shape == want.shape and np.array_equal(got[r][0], want), r
+    assert want[7].any() and want[21].any()
+    if lo < 1e-6:
+        assert got[1][2] > 100   # rows of the second segment really started undetermined
