@@ -604,10 +604,10 @@ def pfb_workload(torch, dev, skip_cpu, n=1 << 26, fs=20e6, steps=10):
         c.batch_process(x)                      # channelizer + TS33C stream decoder on the 64 rows
         if collect is not None:
             collect[chain.DEC_TS33C] = c.fetch_frames()
-        for d in rules:                         # further decoders over the same sliced rows
-            c.redecode(d, rate)
-            if collect is not None:
-                collect[d] = c.fetch_frames()
+        c.redecode_multi(rules, rate)           # the three rule decoders over the same sliced rows, one launch
+        if collect is not None:
+            for k, d in enumerate(rules):
+                collect[d] = c.fetch_frames_multi(k)
 
     for _ in range(3):
         step()
@@ -620,7 +620,7 @@ def pfb_workload(torch, dev, skip_cpu, n=1 << 26, fs=20e6, steps=10):
     dt = (time.perf_counter() - t0) / steps
     front_ms, back_ms = c.profile_read()
     c.profile_enable(False)
-    per = 1 + len(rules)                        # profile slots per step: channelizer pass + one per further decoder
+    per = 2                                     # profile slots per step: channelizer pass + the multi-decoder launch
     front_ms, back_ms = front_ms[0::per], [sum(back_ms[i:i + per]) for i in range(0, len(back_ms) - per + 1, per)]
     got = {}
     step(got)
@@ -641,7 +641,7 @@ def pfb_workload(torch, dev, skip_cpu, n=1 << 26, fs=20e6, steps=10):
     out = {"value": round(n / dt / 1e6, 1), "unit": "Msps", "ms_per_step": round(dt * 1e3, 4), "samples": n,
            "sample_rate": fs, "channels": M, "ntaps": int(taps.size), "keep_n": keep,
            "chain": "pfb64->mag2->threshold->slicer->keep_one_in_n->{ts33c, somfy, berner, mumbi} decoders per channel",
-           "decoder_passes_per_step": 4,
+           "decoder_passes_per_step": 4, "decoder_launches_per_step": 2,
            "roofline": {"bound": "hbm", "kernel": "k_pfb<8>", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                         "traffic": pmc_traffic("k_pfb<8>", "samples=2^%d" % int(np.log2(n)))[0],

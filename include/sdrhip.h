@@ -348,6 +348,12 @@ SDR_API int sdr_pfb_create(const sdr_chain_cfg* cfg, int channels, sdr_handle** 
  * concurrently per channel".  Replaces the frame table. */
 SDR_API int sdr_redecode(sdr_handle* h, int decoder, double decoder_rate);
 
+/* The same for up to 8 decoders in ONE launch (every row x decoder pair is its own workgroup): the frame tables
+ * are kept per decoder, sdr_fetch_frames_multi(k) returns those of decoders[k].  sdr_fetch_frames still
+ * returns the table of the last sdr_batch_process / sdr_redecode. */
+SDR_API int sdr_redecode_multi(sdr_handle* h, const int32_t* decoders, int n, double decoder_rate);
+SDR_API int sdr_fetch_frames_multi(sdr_handle* h, int k, sdr_frame* out, size_t cap, size_t* n);
+
 /* ---- FM-Radio chain (BASELINE.json configs[1]) --------------------------------
  * ref: FM-Radio/FM-Radio.grc:2903-2964 wiring: freq_xlating_fir_filter_ccc
  * (taps 1, center_freq -shift) -> rational_resampler_ccc 1/int(samp_rate/500e3)

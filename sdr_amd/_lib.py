@@ -154,6 +154,7 @@ EXPORTS = [
     "sdr_fm_last_error", "sdr_fm_reset",
     "sdr_pfb_create", "sdr_redecode", "sdr_set_input_format", "sdr_history_len", "sdr_seek", "sdr_segment_info_get", "sdr_export_bits",
     "sdr_batch_process_static", "sdr_static_scratch_bytes", "sdr_segment_info_rows", "sdr_batch_process_bits",
+    "sdr_redecode_multi", "sdr_fetch_frames_multi",
 ]
 
 _lib = None
@@ -249,6 +250,10 @@ def load():
     L.sdr_pfb_create.argtypes = [C.POINTER(ChainCfg), C.c_int, C.POINTER(H)]
     L.sdr_redecode.restype = C.c_int
     L.sdr_redecode.argtypes = [H, C.c_int, C.c_double]
+    L.sdr_redecode_multi.restype = C.c_int
+    L.sdr_redecode_multi.argtypes = [H, C.POINTER(C.c_int32), C.c_int, C.c_double]
+    L.sdr_fetch_frames_multi.restype = C.c_int
+    L.sdr_fetch_frames_multi.argtypes = [H, C.c_int, C.POINTER(Frame), C.c_size_t, C.POINTER(C.c_size_t)]
     L.sdr_set_input_format.restype = C.c_int
     L.sdr_set_input_format.argtypes = [H, C.c_int]
     L.sdr_history_len.restype = C.c_int

@@ -302,6 +302,21 @@ class Chain(object):
         """Run another decoder over the last batch's sliced bytes; then fetch_frames()."""
         _lib.check(self._h, self._L.sdr_redecode(self._h, int(decoder), float(decoder_rate)))
 
+    def redecode_multi(self, decoders, decoder_rate=0.0):
+        """Run several decoders over the last batch's sliced bytes in ONE launch -> [frames of decoders[0], ...]."""
+        arr = (C.c_int32 * len(decoders))(*[int(d) for d in decoders])
+        _lib.check(self._h, self._L.sdr_redecode_multi(self._h, arr, len(decoders), float(decoder_rate)))
+        return self
+
+    def fetch_frames_multi(self, k):
+        n = C.c_size_t()
+        _lib.check(self._h, self._L.sdr_fetch_frames_multi(self._h, int(k), None, 0, C.byref(n)))
+        if n.value == 0:
+            return []
+        buf = (_lib.Frame * n.value)()
+        _lib.check(self._h, self._L.sdr_fetch_frames_multi(self._h, int(k), buf, n.value, C.byref(n)))
+        return [buf[i] for i in range(n.value)]
+
     def decoder_state(self):
         st = (C.c_int32 * 4)()
         _lib.check(self._h, self._L.sdr_decoder_state(self._h, C.byref(st)))

@@ -128,12 +128,17 @@ __global__ void __launch_bounds__(BK_THREADS, 6) k_backend(BackParams P)
     int* s_has = reinterpret_cast<int*>(s_C);
     int* s_last = s_has + BK_THREADS;
 
-    const int cap = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int vcap = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    int cap = vcap;                  // row of the sliced bytes / run table
+    if (P.ndec) {                    // several decoders over the same rows in one launch (P is this kernel's own copy)
+        cap = vcap % P.vrows;
+        P.decoder = P.dec_list[vcap / P.vrows];
+    }
 #ifdef SDR_BK_TIMING
     long long tk0 = __builtin_readcyclecounter(), tk1 = 0, tk2 = 0, tk3 = 0;
 #endif
     int8_t* bits = P.bits + (long long)cap * P.bits_stride;
-    DecState* st = P.st + cap;
+    DecState* st = P.st + vcap;
     // behind a gating squelch every capture of a batch has its own length
     long long nout = P.nout, nb = P.nb;
     int run_decoder = P.run_decoder;
@@ -380,7 +385,7 @@ __global__ void __launch_bounds__(BK_THREADS, 6) k_backend(BackParams P)
     const bool stream_dec = P.decoder <= SDR_DEC_TFA_GRC;
     const int32_t* rpos = pos_in_lds ? s_pos : pos;
     // streaming rule decoders: ticks are absolute, the callback's state comes from / goes to P.rule
-    RuleState* const rs = (!stream_dec && P.decoder != SDR_DEC_VELUX && P.rule) ? P.rule + cap : nullptr;
+    RuleState* const rs = (!stream_dec && P.decoder != SDR_DEC_VELUX && P.rule) ? P.rule + vcap : nullptr;
     const long long rule_base = (rs && rs->valid) ? rs->base : 0;
     if (w_in_lds) {
         if (stream_dec)
@@ -389,7 +394,7 @@ __global__ void __launch_bounds__(BK_THREADS, 6) k_backend(BackParams P)
             for (long long k = tid; k < R; k += BK_THREADS)
                 s_tick[k] = ((rule_base + (long long)rpos[k]) * 1000000LL) / (long long)P.dec_rate;
     }
-    double* gcur = P.cur + (long long)cap * SDR_CUR_CAP;
+    double* gcur = P.cur + (long long)vcap * SDR_CUR_CAP;
     if (stream_dec) {
         const int npend = st->n_cur;
         for (int k = tid; k < npend && k < SDR_CUR_CAP; k += BK_THREADS) s_cur[k] = gcur[k];
@@ -407,9 +412,9 @@ __global__ void __launch_bounds__(BK_THREADS, 6) k_backend(BackParams P)
     if (stream_dec) {
         WaveLds L{s_cur, s_scratch, s_words, s_par};
         if (w_in_lds)
-            wave_stream_decode(P, cap, WidthsArray{s_w}, pos, R, first_level, last_level, any_one, L, &ls);
+            wave_stream_decode(P, vcap, WidthsArray{s_w}, pos, R, first_level, last_level, any_one, L, &ls);
         else
-            wave_stream_decode(P, cap, WidthsFromPos{pos, P.dec_rate}, pos, R, first_level, last_level, any_one, L,
+            wave_stream_decode(P, vcap, WidthsFromPos{pos, P.dec_rate}, pos, R, first_level, last_level, any_one, L,
                                &ls);
         for (int k = tid; k < ls.n_cur; k += 64) gcur[k] = s_cur[k];
     } else {
@@ -418,17 +423,17 @@ __global__ void __launch_bounds__(BK_THREADS, 6) k_backend(BackParams P)
         // hit the same addresses with the same data
         EdgeCtx e{pos_in_lds ? s_pos : pos, w_in_lds ? s_tick : nullptr, R, nb, first_level, (long long)P.dec_rate, 1, rule_base, rs};
         if (P.decoder == SDR_DEC_SOMFY)
-            rule_somfy(e, P, &ls, cap, s_bits);
+            rule_somfy(e, P, &ls, vcap, s_bits);
         else if (P.decoder == SDR_DEC_BERNER)
-            rule_berner(e, P, &ls, cap, s_bits);
+            rule_berner(e, P, &ls, vcap, s_bits);
         else if (P.decoder == SDR_DEC_MUMBI)
-            rule_mumbi(e, P, &ls, cap, s_bits);
+            rule_mumbi(e, P, &ls, vcap, s_bits);
         else if (P.decoder == SDR_DEC_KWMOBILE)
-            rule_kwmobile(e, P, &ls, cap, s_bits);
+            rule_kwmobile(e, P, &ls, vcap, s_bits);
         else if (P.decoder == SDR_DEC_BALDR)
-            rule_baldr(e, P, &ls, cap, s_bits);
+            rule_baldr(e, P, &ls, vcap, s_bits);
         else if (P.decoder == SDR_DEC_VELUX)
-            rule_velux(e, P, &ls, cap);
+            rule_velux(e, P, &ls, vcap);
     }
     if (tid == 0) *st = ls;
 #ifdef SDR_BK_TIMING

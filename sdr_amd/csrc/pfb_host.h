@@ -270,3 +270,116 @@ extern "C" int sdr_redecode(sdr_handle* h, int decoder, double decoder_rate)
     h->dec_rate = keep_rate;
     return r;
 }
+
+// Several decoders over the sliced rows of the last batch in ONE launch: workgroup v decodes row v % rows
+// with decoders[v / rows], each from a fresh decoder object; the run table of the batch's own pass is reused.
+// Four k_backend launches over the 64 channel rows cost 0.15 ms (latency-bound, 64 workgroups each); one
+// launch of 64 x n workgroups costs what one of them did.
+extern "C" int sdr_redecode_multi(sdr_handle* h, const int32_t* decoders, int n, double decoder_rate)
+{
+    if (!h || !decoders || n < 1 || n > 8) return fail(h, SDR_E_ARG, "sdr_redecode_multi: 1..8 decoders");
+    for (int i = 0; i < n; ++i)
+        if (decoders[i] <= SDR_DEC_NONE || decoders[i] > SDR_DEC_VELUX) return fail(h, SDR_E_ARG, "sdr_redecode_multi: bad decoder");
+    if (h->cfg.demod == SDR_DEMOD_NONE || h->skip_slice) return fail(h, SDR_E_ARG, "sdr_redecode_multi: the chain has no sliced stream");
+    if (h->last_ncap < 1) return fail(h, SDR_E_ARG, "sdr_redecode_multi: no batch processed yet");
+    if (h->last_bits_off != 0 || h->raw_n != 0) return fail(h, SDR_E_ARG, "sdr_redecode_multi: only after sdr_batch_process");
+    (void)hipSetDevice(h->device);
+    const int rows = h->last_ncap;
+    const long long need = (long long)rows * n;
+    if (need > h->m_cap) {
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        for (void* p : {(void*)h->d_m_cur, (void*)h->d_m_st, (void*)h->d_m_frames})
+            if (p) (void)hipFree(p);
+        h->d_m_cur = nullptr;
+        h->d_m_st = nullptr;
+        h->d_m_frames = nullptr;
+        h->m_cap = 0;
+        HIPCHK(h, dev_alloc((void**)&h->d_m_cur, (size_t)(need * SDR_CUR_CAP) * sizeof(double)));
+        HIPCHK(h, dev_alloc((void**)&h->d_m_st, (size_t)need * sizeof(DecState)));
+        HIPCHK(h, dev_alloc((void**)&h->d_m_frames, (size_t)(need * h->cfg.max_frames) * sizeof(sdr_frame)));
+        HIPCHK(h, hipMemset(h->d_m_frames, 0, (size_t)(need * h->cfg.max_frames) * sizeof(sdr_frame)));
+        h->m_cap = need;
+    }
+    const double rate = decoder_rate > 0 ? decoder_rate : h->dec_rate;
+    if (!h->runs_valid) {
+        // no run table from the batch's own pass (it ran without a decoder): one ordinary pass builds it
+        int r = sdr_redecode(h, decoders[0], decoder_rate);
+        if (r) return r;
+        if (!h->runs_valid) return fail(h, SDR_E_ARG, "sdr_redecode_multi: rows too short for the first decoder's pass");
+    }
+    BackParams Bp;
+    memset(&Bp, 0, sizeof Bp);
+    Bp.bits = h->d_bits;
+    Bp.bits_stride = h->bits_stride;
+    Bp.nb = h->last_nb;
+    Bp.keep_n = h->cfg.keep_n;
+    Bp.thr_init = h->cfg.thr_init;
+    Bp.run_decoder = 1;
+    Bp.decoder = decoders[0];
+    Bp.fresh = 1;
+    Bp.dec_rate = rate;
+    Bp.runs = h->d_runs;
+    Bp.runs_cap = h->runs_cap;
+    Bp.cur = h->d_m_cur;
+    Bp.st = h->d_m_st;
+    Bp.frames = h->d_m_frames;
+    Bp.max_frames = h->cfg.max_frames;
+    Bp.pow_m13 = h->d_pow;
+    Bp.log2n = h->d_log2;
+    Bp.runs_n = h->d_runs_n;
+    Bp.reuse_runs = 1;
+    Bp.ndec = n;
+    Bp.vrows = rows;
+    for (int i = 0; i < n; ++i) Bp.dec_list[i] = decoders[i];
+    // a stream decoder on rows shorter than its reset_limit would only fill its rawBuffer: nothing to report
+    for (int i = 0; i < n; ++i)
+        if (is_stream_decoder(decoders[i]) && !((double)Bp.nb * 1e6 / rate > decoder_reset_limit(decoders[i])))
+            return fail(h, SDR_E_ARG, "sdr_redecode_multi: rows shorter than a stream decoder's reset limit");
+    if (h->profile) {
+        HIPCHK(h, hipEventRecord(h->pev[3 * (h->pcount % SDR_PROF_RING)], h->stream));
+        HIPCHK(h, hipEventRecord(h->pev[3 * (h->pcount % SDR_PROF_RING) + 1], h->stream));
+    }
+    hipLaunchKernelGGL(k_backend, dim3((unsigned)need), dim3(BK_THREADS), 0, h->stream, Bp);
+    HIPCHK(h, hipGetLastError());
+    if (h->profile) {
+        HIPCHK(h, hipEventRecord(h->pev[3 * (h->pcount % SDR_PROF_RING) + 2], h->stream));
+        h->pcount++;
+    }
+    h->m_ndec = n;
+    h->m_rows = rows;
+    return SDR_OK;
+}
+
+// frames of decoder number k (0-based position in the list) of the last sdr_redecode_multi
+extern "C" int sdr_fetch_frames_multi(sdr_handle* h, int k, sdr_frame* outp, size_t cap, size_t* n)
+{
+    if (!h || !n || k < 0 || k >= h->m_ndec) return fail(h, SDR_E_ARG, "sdr_fetch_frames_multi: bad argument");
+    (void)hipSetDevice(h->device);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const int B = h->m_rows;
+    *n = 0;
+    std::vector<DecState> st(B);
+    HIPCHK(h, hipMemcpy(st.data(), h->d_m_st + (size_t)k * B, (size_t)B * sizeof(DecState), hipMemcpyDeviceToHost));
+    size_t total = 0;
+    int overflow = 0;
+    for (int i = 0; i < B; ++i) {
+        total += st[i].n_frames;
+        overflow |= st[i].overflow;
+    }
+    *n = total;
+    if (outp && cap) {
+        std::vector<sdr_frame> all((size_t)B * h->cfg.max_frames);
+        HIPCHK(h, hipMemcpy(all.data(), h->d_m_frames + (size_t)k * B * h->cfg.max_frames, all.size() * sizeof(sdr_frame),
+                            hipMemcpyDeviceToHost));
+        size_t j2 = 0;
+        for (int i = 0; i < B && j2 < cap; ++i)
+            for (int j = 0; j < st[i].n_frames && j2 < cap; ++j) {
+                outp[j2] = all[(size_t)i * h->cfg.max_frames + j];
+                outp[j2].capture = i;   // the kernel numbered the virtual capture (row + k*rows)
+                ++j2;
+            }
+    }
+    if (overflow) return fail(h, SDR_E_OVERFLOW, "device table overflow (runs/frames/symbols), code " + std::to_string(overflow));
+    return SDR_OK;
+}
+

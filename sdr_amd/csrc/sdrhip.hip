@@ -71,6 +71,12 @@ struct sdr_handle {
     long long runs_cap = 0;
     double* d_cur = nullptr;
     DecState* d_st = nullptr;
+    // sdr_redecode_multi: tables for rows x decoders virtual captures
+    double* d_m_cur = nullptr;
+    DecState* d_m_st = nullptr;
+    sdr_frame* d_m_frames = nullptr;
+    long long m_cap = 0;
+    int m_ndec = 0, m_rows = 0;
     RuleState* d_rule = nullptr;    // callback-rule decoders: state between streaming calls (one per streaming row)
     size_t rule_rows = 1;
     sdr_frame* d_frames = nullptr;
@@ -471,7 +477,7 @@ extern "C" int sdr_destroy(sdr_handle* h)
     if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
     void* ptrs[] = {h->d_rtaps, h->d_post_rtaps, h->d_nco_tab, h->d_atan_tab, h->d_pow, h->d_log2, h->d_iq,
                     h->d_hist[0], h->d_hist[1], h->d_bits, h->d_tap, h->d_tap2, h->d_tsum, h->d_runs, h->d_runs_seg, h->d_seg_cnt, h->d_runs_n, h->d_pieces_hdr,
-                    h->d_cur, h->d_st, h->d_rule, h->d_frames, h->d_sq_y, h->d_sq_z, h->d_sq_cnt, h->d_sq_st,
+                    h->d_cur, h->d_st, h->d_rule, h->d_frames, h->d_m_cur, h->d_m_st, h->d_m_frames, h->d_sq_y, h->d_sq_z, h->d_sq_cnt, h->d_sq_st,
                     h->d_post_hist[0], h->d_post_hist[1], h->d_pack, h->d_pfb_taps, h->d_pfb_tw};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);

@@ -72,6 +72,21 @@ def test_pfb_wideband_emitters_decode_per_channel(kat):
         f_kw = c.fetch_frames()
         c.redecode(chain.DEC_MUMBI)
         f_mu = c.fetch_frames()
+        # all of them (and two more) in ONE launch: identical frame records per decoder
+        import ctypes as C
+
+        def rec(fr):
+            return [bytes(bytearray(C.string_at(C.byref(f), C.sizeof(f)))) for f in fr]
+        decs = [chain.DEC_TS33C, chain.DEC_KWMOBILE, chain.DEC_MUMBI, chain.DEC_SOMFY, chain.DEC_BERNER]
+        c.redecode_multi(decs)
+        multi = [c.fetch_frames_multi(k) for k in range(len(decs))]
+        assert rec(multi[0]) == rec(f_ts) and rec(multi[1]) == rec(f_kw) and rec(multi[2]) == rec(f_mu)
+        c.redecode(chain.DEC_BERNER)
+        assert rec(multi[4]) == rec(c.fetch_frames())
+        c.redecode(chain.DEC_SOMFY)
+        assert rec(multi[3]) == rec(c.fetch_frames())
+        c.batch_process(x[None, :])                  # the handle's own tables are untouched by the multi pass
+        assert rec(c.fetch_frames()) == rec(f_ts)
     o = odec.TS33CStreamDecoder(sample_rate=rate)
     o.work([want[5]])
     good = [f for f in f_ts if f.status == 0]
