@@ -560,14 +560,10 @@ def mixed_emitters_workload(torch, dev, skip_cpu, ncap=1250, n=N_PER_CAPTURE, fs
     return out
 
 
-def pfb_workload(torch, dev, skip_cpu, n=1 << 26, fs=20e6, steps=10):
-    """Secondary line (BASELINE.json configs[4]): one 2^26-sample wideband capture at 20 Msps
-    -> 64 sub-bands of 312.5 kHz (481-tap prototype, 8 per branch) -> mag^2 -> threshold ->
-    slicer -> keep_one_in_n(16) -> the TS33C stream decoder and the somfy / berner / mumbi rule decoders
-    over every channel (sdr_redecode); a TS33C, a berner and a mumbi transmitter sit in three sub-bands."""
-    from sdr_amd import chain, synth, _lib
-    M, keep = 64, 16
-    rate = fs / M / keep
+def make_wideband(torch, dev, n=1 << 26, fs=20e6, M=64):
+    """One wideband capture: noise + a TS33C, a berner and a mumbi transmitter in three of the 64 sub-bands.
+    -> (iq [n, 2] on the GPU, dict of what was transmitted where)"""
+    from sdr_amd import synth
     rng = np.random.default_rng(64)
     pkt = synth.ts33c_packet(**synth.random_ts33c_fields(rng))
     sym = []
@@ -593,6 +589,19 @@ def pfb_workload(torch, dev, skip_cpu, n=1 << 26, fs=20e6, steps=10):
             iq[a:a + step_n, 0] += e * torch.cos(ph).to(torch.float32)
             iq[a:a + step_n, 1] += e * torch.sin(ph).to(torch.float32)
         del env
+    return iq, {"ts33c": (ch, pkt), "berner": (ch_berner, berner_code), "mumbi": (ch_mumbi, mumbi_want)}
+
+
+def pfb_workload(torch, dev, skip_cpu, n=1 << 26, fs=20e6, steps=10):
+    """Secondary line (BASELINE.json configs[4]): one 2^26-sample wideband capture at 20 Msps
+    -> 64 sub-bands of 312.5 kHz (481-tap prototype, 8 per branch) -> mag^2 -> threshold ->
+    slicer -> keep_one_in_n(16) -> the TS33C stream decoder and the somfy / berner / mumbi rule decoders
+    over every channel (sdr_redecode_multi); a TS33C, a berner and a mumbi transmitter sit in three sub-bands."""
+    from sdr_amd import chain, synth, _lib
+    M, keep = 64, 16
+    rate = fs / M / keep
+    iq, sent = make_wideband(torch, dev, n, fs, M)
+    (ch, pkt), (ch_berner, berner_code), (ch_mumbi, mumbi_want) = sent["ts33c"], sent["berner"], sent["mumbi"]
     taps = chain.low_pass(1.0, fs, 100e3, 100e3)
     c = chain.Chain(fs, taps=taps, keep_n=keep, decoder=chain.DEC_TS33C, decoder_rate=rate, max_samples=n,
                     max_frames=64, channels=M)

@@ -436,6 +436,16 @@ SDR_HD inline int sat_delta(long long d) { return d > 0x7fffffffLL ? 0x7fffffff 
 SDR_HD inline bool in_range(int d, int a, int b) { return d >= a && d < b; }
 SDR_HD inline bool in_range(long long d, long long a, long long b) { return d >= a && d < b; }
 
+// The decoder this workgroup runs: P.decoder, or -- sdr_redecode_multi, one launch for several decoders --
+// its entry of dec_list (wave-uniform; P itself stays an unmodified kernel argument in scalar registers).
+SDR_HD inline int dec_of(const BackParams& P)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (P.ndec) return (int)((P.dec_pack >> (4u * (blockIdx.x / (unsigned)P.vrows))) & 15u);
+#endif
+    return P.decoder;
+}
+
 SDR_HD inline sdr_frame* next_frame(const BackParams& P, DecState* st, int cap, long long end_pos)
 {
     if (st->n_frames >= P.max_frames) {
@@ -444,7 +454,7 @@ SDR_HD inline sdr_frame* next_frame(const BackParams& P, DecState* st, int cap, 
     }
     sdr_frame* f = P.frames + (long long)cap * P.max_frames + st->n_frames;
     st->n_frames++;
-    frame_init(f, cap, P.decoder, end_pos);
+    frame_init(f, cap, dec_of(P), end_pos);
     return f;
 }
 
@@ -1260,7 +1270,7 @@ SDR_HD inline void stream_decode(const BackParams& P, int cap, WF W, const int32
                                  int first_level, int last_level, bool any_one, double* cur,
                                  DecState* st, double* scratch)
 {
-    const bool ts33c = (P.decoder == SDR_DEC_TS33C);
+    const bool ts33c = (dec_of(P) == SDR_DEC_TS33C);
     const double reset_limit = ts33c ? 1550.0 : 500.0;
     // skip empty or zero-only chunks (:50)
     if (!(P.nb > 0 && (any_one || st->n_cur > 0))) {
@@ -1309,7 +1319,7 @@ SDR_HD inline void stream_decode(const BackParams& P, int cap, WF W, const int32
                     if (ts33c)
                         decode_ts33c(cur, st->n_cur, reset_limit, scratch, st, P, f);
                     else
-                        decode_tfa(cur, st->n_cur, scratch, P.decoder == SDR_DEC_TFA_GRC, f);
+                        decode_tfa(cur, st->n_cur, scratch, dec_of(P) == SDR_DEC_TFA_GRC, f);
                 }
                 st->n_cur = 0;  // done with this packet (:204)
             }

@@ -130,10 +130,7 @@ __global__ void __launch_bounds__(BK_THREADS, 6) k_backend(BackParams P)
 
     const int vcap = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     int cap = vcap;                  // row of the sliced bytes / run table
-    if (P.ndec) {                    // several decoders over the same rows in one launch (P is this kernel's own copy)
-        cap = vcap % P.vrows;
-        P.decoder = P.dec_list[vcap / P.vrows];
-    }
+    if (P.ndec) cap = vcap % P.vrows;   // several decoders over the same rows in one launch: dec_of(P) picks this workgroup's
 #ifdef SDR_BK_TIMING
     long long tk0 = __builtin_readcyclecounter(), tk1 = 0, tk2 = 0, tk3 = 0;
 #endif
@@ -145,8 +142,8 @@ __global__ void __launch_bounds__(BK_THREADS, 6) k_backend(BackParams P)
     if (P.nout_var) {
         nout = P.nout_var[cap];
         nb = P.patch_off + (nout > P.keep_c0 ? (nout - P.keep_c0 + P.keep_n - 1) / P.keep_n : 0);
-        if (P.decoder >= SDR_DEC_TS33C && P.decoder <= SDR_DEC_TFA_GRC)
-            run_decoder = ((double)nb * 1e6 / P.dec_rate > (P.decoder == SDR_DEC_TS33C ? 1550.0 : 500.0)) ? 1 : 0;
+        if (dec_of(P) >= SDR_DEC_TS33C && dec_of(P) <= SDR_DEC_TFA_GRC)
+            run_decoder = ((double)nb * 1e6 / P.dec_rate > (dec_of(P) == SDR_DEC_TS33C ? 1550.0 : 500.0)) ? 1 : 0;
     }
 
     if (tid == 0) {
@@ -236,7 +233,7 @@ __global__ void __launch_bounds__(BK_THREADS, 6) k_backend(BackParams P)
             st->first_evt = fe;
         }
     }
-    if (!run_decoder || P.decoder == SDR_DEC_NONE || P.phase_sel == 1) return;
+    if (!run_decoder || dec_of(P) == SDR_DEC_NONE || P.phase_sel == 1) return;
     __syncthreads();
 #ifdef SDR_BK_TIMING
     tk1 = __builtin_readcyclecounter();
@@ -382,10 +379,10 @@ __global__ void __launch_bounds__(BK_THREADS, 6) k_backend(BackParams P)
     if (nb == 0) return;
 
     // run widths (stream decoders) or edge ticks (callback rules) into LDS
-    const bool stream_dec = P.decoder <= SDR_DEC_TFA_GRC;
+    const bool stream_dec = dec_of(P) <= SDR_DEC_TFA_GRC;
     const int32_t* rpos = pos_in_lds ? s_pos : pos;
     // streaming rule decoders: ticks are absolute, the callback's state comes from / goes to P.rule
-    RuleState* const rs = (!stream_dec && P.decoder != SDR_DEC_VELUX && P.rule) ? P.rule + vcap : nullptr;
+    RuleState* const rs = (!stream_dec && dec_of(P) != SDR_DEC_VELUX && P.rule) ? P.rule + vcap : nullptr;
     const long long rule_base = (rs && rs->valid) ? rs->base : 0;
     if (w_in_lds) {
         if (stream_dec)
@@ -422,17 +419,17 @@ __global__ void __launch_bounds__(BK_THREADS, 6) k_backend(BackParams P)
         // scalar branches instead of exec masking, every LDS read is a broadcast; the redundant stores
         // hit the same addresses with the same data
         EdgeCtx e{pos_in_lds ? s_pos : pos, w_in_lds ? s_tick : nullptr, R, nb, first_level, (long long)P.dec_rate, 1, rule_base, rs};
-        if (P.decoder == SDR_DEC_SOMFY)
+        if (dec_of(P) == SDR_DEC_SOMFY)
             rule_somfy(e, P, &ls, vcap, s_bits);
-        else if (P.decoder == SDR_DEC_BERNER)
+        else if (dec_of(P) == SDR_DEC_BERNER)
             rule_berner(e, P, &ls, vcap, s_bits);
-        else if (P.decoder == SDR_DEC_MUMBI)
+        else if (dec_of(P) == SDR_DEC_MUMBI)
             rule_mumbi(e, P, &ls, vcap, s_bits);
-        else if (P.decoder == SDR_DEC_KWMOBILE)
+        else if (dec_of(P) == SDR_DEC_KWMOBILE)
             rule_kwmobile(e, P, &ls, vcap, s_bits);
-        else if (P.decoder == SDR_DEC_BALDR)
+        else if (dec_of(P) == SDR_DEC_BALDR)
             rule_baldr(e, P, &ls, vcap, s_bits);
-        else if (P.decoder == SDR_DEC_VELUX)
+        else if (dec_of(P) == SDR_DEC_VELUX)
             rule_velux(e, P, &ls, vcap);
     }
     if (tid == 0) *st = ls;

@@ -311,7 +311,7 @@ __device__ inline void wave_stream_decode(const BackParams& P, int cap, WF W, co
                                           DecState* st)
 {
     const int lane = threadIdx.x & 63;
-    const bool ts33c = (P.decoder == SDR_DEC_TS33C);
+    const bool ts33c = (dec_of(P) == SDR_DEC_TS33C);
     const double reset_limit = ts33c ? 1550.0 : 500.0;
     if (!(R > 0 && (any_one || st->n_cur > 0))) {
         st->state = 0;
@@ -428,14 +428,14 @@ __device__ inline void wave_stream_decode(const BackParams& P, int cap, WF W, co
                 else {
                     f = P.frames + (long long)cap * P.max_frames + st->n_frames;
                     st->n_frames++;
-                    if (lane == 0) frame_init(f, cap, P.decoder, pos[b]);
+                    if (lane == 0) frame_init(f, cap, dec_of(P), pos[b]);
                 }
                 wave_sync();
                 if (f) {
                     if (ts33c)
                         wave_decode_ts33c(L, st->n_cur, reset_limit, st, P, f);
                     else
-                        wave_decode_tfa(L, st->n_cur, P.decoder == SDR_DEC_TFA_GRC, f);
+                        wave_decode_tfa(L, st->n_cur, dec_of(P) == SDR_DEC_TFA_GRC, f);
                 }
                 st->n_cur = 0;
             }
@@ -464,7 +464,7 @@ __global__ void __launch_bounds__(64) k_decode_pieces(BackParams P)
     const int32_t* pb = P.pieces_b + (long long)cap * P.bits_stride;
     const int32_t* pos = P.runs + (long long)cap * (P.runs_cap + 2);
     const WidthsFromPos W{pos, P.dec_rate};
-    const bool ts33c = P.decoder == SDR_DEC_TS33C;
+    const bool ts33c = dec_of(P) == SDR_DEC_TS33C;
     const long long total = f1 + nf_mid > P.max_frames ? P.max_frames : f1 + nf_mid;
     DecState* st = P.st + cap;
     const WaveLds L{s_cur, s_scr, s_words, s_par};
@@ -481,7 +481,7 @@ __global__ void __launch_bounds__(64) k_decode_pieces(BackParams P)
         if (slot >= P.max_frames) continue;
         for (long long t = lane; t < len; t += 64) s_cur[t] = W(a + t);
         sdr_frame* f = P.frames + (long long)cap * P.max_frames + slot;
-        if (lane == 0) frame_init(f, cap, P.decoder, pos[b]);
+        if (lane == 0) frame_init(f, cap, dec_of(P), pos[b]);
         wave_sync();
         if (ts33c) {
             DecState tmp;
@@ -493,7 +493,7 @@ __global__ void __launch_bounds__(64) k_decode_pieces(BackParams P)
                 st->gap_short_limit = tmp.gap_short_limit;
             }
         } else
-            wave_decode_tfa(L, (int)len, P.decoder == SDR_DEC_TFA_GRC, f);
+            wave_decode_tfa(L, (int)len, dec_of(P) == SDR_DEC_TFA_GRC, f);
         wave_sync();
     }
 }

@@ -330,7 +330,7 @@ extern "C" int sdr_redecode_multi(sdr_handle* h, const int32_t* decoders, int n,
     Bp.reuse_runs = 1;
     Bp.ndec = n;
     Bp.vrows = rows;
-    for (int i = 0; i < n; ++i) Bp.dec_list[i] = decoders[i];
+    for (int i = 0; i < n; ++i) Bp.dec_pack |= (unsigned)decoders[i] << (4 * i);
     // a stream decoder on rows shorter than its reset_limit would only fill its rawBuffer: nothing to report
     for (int i = 0; i < n; ++i)
         if (is_stream_decoder(decoders[i]) && !((double)Bp.nb * 1e6 / rate > decoder_reset_limit(decoders[i])))

@@ -181,10 +181,12 @@ struct BackParams {
     // k_decode_pieces, one wavefront each
     int32_t* pieces_b;      // per capture (bits_stride ints, the runs_seg slice): run index behind every over-limit width
     int32_t* pieces_hdr;    // per capture 8 ints: [0] 1 = delegated, [1] over-limit widths, [2] frames of the first piece, [3] frames of the middle pieces
-    // sdr_redecode_multi: workgroup v decodes row v % vrows with decoder dec_list[v / vrows]; DecState, pending
-    // symbols and frame table are indexed by v (ndec == 0: one decoder, v == row)
+    // sdr_redecode_multi: workgroup v decodes row v % vrows with decoder number v / vrows of dec_pack (4 bits
+    // each; NOT an array: indexing a by-value kernel argument dynamically sends the whole struct to scratch
+    // memory -- measured: every k_backend launch 2.4x slower); DecState, pending symbols and frame table are
+    // indexed by v (ndec == 0: one decoder, v == row)
     int ndec;
     int vrows;
-    int dec_list[8];
+    unsigned int dec_pack;
     RuleState* rule;        // streaming call with a callback-rule decoder: per-row state between calls; nullptr = one call per capture
 };

@@ -17,6 +17,7 @@ KERNELS = {
     "_Z15k_frontend_mfma11FrontParams": "k_frontend_mfma",
     "_Z15k_frontend_raw811FrontParams10FrontKTaps": "k_frontend_raw8",
     "_Z5k_pfbILi8EEv9PfbParams": "k_pfb<8>",
+    "_Z14k_frontend_win11FrontParams": "k_frontend_win",
 }
 
 
@@ -62,3 +63,17 @@ def test_no_vmcnt_wait_inside_the_dma_loop(device_asm, sym):
         assert not waits, "%s: the staging loop waits on its own DMA: %s" % (KERNELS[sym], waits)
         others = [l.strip() for l in body if re.search(r"\b(global_load_dword|global_load_u|buffer_load|flat_load)", l)]
         assert not others, "%s: other loads share the DMA loop: %s" % (KERNELS[sym], others)
+
+
+def test_hot_kernels_use_no_scratch_memory(device_asm):
+    """Round 2: a dynamically indexed array inside the by-value BackParams argument sent the whole struct to
+    private (scratch) memory -- every k_backend launch 2.4x slower, identical results.  The kernels on the
+    measured paths must keep their state in registers: private_segment_fixed_size == 0."""
+    hot = ["_Z9k_backend10BackParams", "_Z14k_frontend_win11FrontParams", "_Z15k_frontend_mfma11FrontParams",
+           "_Z10k_frontendILb1ELb0EEv11FrontParams10FrontKTaps", "_Z15k_frontend_raw811FrontParams10FrontKTaps",
+           "_Z5k_pfbILi8EEv9PfbParams", "_Z10k_runs_seg10BackParams", "_Z15k_decode_pieces10BackParams"]
+    for sym in hot:
+        i = device_asm.index(".amdhsa_kernel " + sym)
+        blk = device_asm[i:device_asm.index(".end_amdhsa_kernel", i)]
+        m = re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", blk)
+        assert m and int(m.group(1)) == 0, "%s uses %s bytes of scratch per lane" % (sym, m.group(1) if m else "?")
