@@ -277,7 +277,7 @@ SDR_API int sdr_export_frames(sdr_handle* h, void* frames_dev, size_t frames_byt
  * Limits: plain chains only (channel filter -> MAG2/QUAD -> slicer -> decoder; no
  * prefilter, squelch, post-demod filter, channelizer, demod tap); the batch's
  * tables must fit the static array (about 60 KiB per capture of 2^18 samples at
- * decimation 50) and a row must stay below 128 KiB of sliced bytes, else
+ * decimation 50) and a row must stay below 32 KiB of sliced bytes, else
  * SDR_E_CAPACITY.  All calls on one GPU share that GPU's array: calls that overlap
  * on one GPU (different handles / streams) race -- serialise them.  The handle's
  * own results (sdr_fetch_*) are left as they were. */

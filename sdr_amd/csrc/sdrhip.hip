@@ -24,6 +24,8 @@
 #define M_PI 3.14159265358979323846
 #endif
 
+#define SDR_PROF_RING 256
+#define SDR_SEG_MIN_ROW (32 * 1024)    // sliced rows this long take the segment- and piece-parallel back end (r02: 128 -> 32 KiB, the channelizer rows)
 struct sdr_handle {
     sdr_chain_cfg cfg;
     int device = 0;
@@ -110,6 +112,7 @@ struct sdr_handle {
     // read ONCE in sdr_create, never on the call path
     bool no_ktaps = false, no_raw8 = false, no_reuse = false, no_seg = false, no_pieces = false;
     int tile_override = 0;
+    long long seg_min_row = SDR_SEG_MIN_ROW;   // rows this long take the segment- and piece-parallel back end (env SDR_SEG_MIN)
 
     // internal modes used by the FM chain (fm_host.h)
     bool prerotate = false;   // center_freq applies to the INPUT samples (xlating taps=[1] then FIR)
@@ -128,8 +131,6 @@ struct sdr_handle {
     std::vector<hipEvent_t> pev;   // 3 events per slot: front start, front end/back start, back end
     unsigned long long pcount = 0;
 };
-#define SDR_PROF_RING 256
-#define SDR_SEG_MIN_ROW (128 * 1024)   // sliced rows this long take the segment-parallel run-length path
 
 static thread_local std::string g_err;
 
@@ -520,6 +521,7 @@ extern "C" int sdr_create(const sdr_chain_cfg* cfg, sdr_handle** out)
     h->no_seg = getenv("SDR_NO_SEG") != nullptr;
     h->no_pieces = getenv("SDR_NO_PIECES") != nullptr;
     if (const char* te = getenv("SDR_TILE")) h->tile_override = atoi(te);
+    if (const char* te = getenv("SDR_SEG_MIN")) h->seg_min_row = atoll(te) >= 16384 ? atoll(te) : 16384;
     (void)hipDeviceGetAttribute(&h->num_cus, hipDeviceAttributeMultiprocessorCount, h->device);
     if (h->num_cus < 1) h->num_cus = 256;
     int rc = SDR_OK;
@@ -572,7 +574,7 @@ extern "C" int sdr_create(const sdr_chain_cfg* cfg, sdr_handle** out)
         h->runs_cap = h->bits_stride;
         HIPCHK(h, dev_alloc((void**)&h->d_runs, (size_t)(B * (h->runs_cap + 2)) * sizeof(int32_t)));
         HIPCHK(h, dev_alloc((void**)&h->d_runs_n, (size_t)B * sizeof(int32_t)));
-        if (h->bits_stride >= SDR_SEG_MIN_ROW) {
+        if (h->bits_stride >= h->seg_min_row) {
             HIPCHK(h, dev_alloc((void**)&h->d_runs_seg, (size_t)(B * h->bits_stride) * sizeof(int32_t)));
             HIPCHK(h, dev_alloc((void**)&h->d_seg_cnt, (size_t)(B * BK_THREADS) * sizeof(int32_t)));
             HIPCHK(h, dev_alloc((void**)&h->d_pieces_hdr, (size_t)(B * 8) * sizeof(int32_t)));
@@ -1024,7 +1026,7 @@ static int launch_back(sdr_handle* h, int ncap, const CallGeom& g, long long pat
     if (h->reuse_next && h->runs_valid && full_pass && !h->no_reuse) {
         Bp.reuse_runs = 1;
         hipLaunchKernelGGL(k_backend, dim3(ncap), dim3(BK_THREADS), 0, h->stream, Bp);
-    } else if (h->d_runs_seg && !Bp.nout_var && run_decoder && c.decoder != SDR_DEC_NONE && nb_total >= SDR_SEG_MIN_ROW &&
+    } else if (h->d_runs_seg && !Bp.nout_var && run_decoder && c.decoder != SDR_DEC_NONE && nb_total >= h->seg_min_row &&
         !h->no_seg) {
         // long rows: carries first (they patch the bytes), then the run starts of every 64-KiB-or-more
         // segment by its own workgroup, then the decoders on the gathered run table
@@ -1752,7 +1754,7 @@ extern "C" int sdr_batch_process_static(sdr_handle* h, const void* iq_dev, size_
     const size_t o_frames = carve((size_t)(B * c.max_frames) * sizeof(sdr_frame));
     if (off > SDR_STATIC_SCRATCH_BYTES || bstride >= SDR_SEG_MIN_ROW)
         return fail(h, SDR_E_CAPACITY, "sdr_batch_process_static: this batch needs " + std::to_string(off) + " bytes of scratch, the static array holds " +
-                                       std::to_string(SDR_STATIC_SCRATCH_BYTES) + " (and rows must stay below 128 KiB of sliced bytes); use sdr_batch_process");
+                                       std::to_string(SDR_STATIC_SCRATCH_BYTES) + " (and rows must stay below 32 KiB of sliced bytes); use sdr_batch_process");
     if (bits_cap < (size_t)(B * g.ne) || frames_cap < (size_t)(B * c.max_frames))
         return fail(h, SDR_E_CAPACITY, "sdr_batch_process_static: output buffer too small");
     unsigned char* const base = g_scratch_ptr[h->device];   // never the array's name: that is a host-side stand-in
