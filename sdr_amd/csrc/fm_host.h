@@ -13,6 +13,7 @@ struct sdr_fm {
     std::string err;
     float *d_ataps = nullptr, *d_rtaps = nullptr;  // audio FIR (reversed), resampler taps
     int n_ataps = 0, n_rtaps = 0, L = 1, M = 1;
+    bool audio_valu = false;                  // SDR_FM_AUDIO=valu: tuning/test override, read once at create
     double b0 = 0, p1 = 0;
     float *d_a2 = nullptr, *d_a3 = nullptr, *d_audio = nullptr;
     long long n1 = 0, n2 = 0, n4 = 0, cap2 = 0, cap4 = 0;
@@ -134,6 +135,7 @@ extern "C" int sdr_fm_create(const sdr_fm_cfg* cfg, sdr_fm** out)
                                  buf.data(), (int)buf.size());
         if (nt < 1) return fm_fail(h, SDR_E_ARG, "audio filter design failed");
         h->n_ataps = nt;
+        if (const char* e = getenv("SDR_FM_AUDIO")) h->audio_valu = !strcmp(e, "valu");
         std::vector<float> rt(nt);
         for (int k = 0; k < nt; ++k) rt[nt - 1 - k] = buf[k];
         FMCHK(h, dev_alloc((void**)&h->d_ataps, nt * sizeof(float)));
@@ -257,14 +259,27 @@ extern "C" int sdr_fm_process(sdr_fm* h, const void* iq, size_t n, int is_dev, s
     h->n2 = (long long)(c_end - h->c_out);
     if (h->n2 > h->cap2) return fm_fail(h, SDR_E_CAPACITY, "sdr_fm_process: audio buffer too small");
     if (h->n2 > 0) {
-        const int T = 256;
-        size_t lds = ((size_t)(T - 1) * D + h->n_ataps) * sizeof(float);
-        int blocks = (int)((h->n2 + T - 1) / T);
         const long long in0 = (long long)(h->c_out * (unsigned long long)D) - (long long)h->c_in;
         const int hv = h->c_in < (unsigned long long)h->chist_len ? (int)h->c_in : h->chist_len;
-        hipLaunchKernelGGL(k_fir_fff_decim, dim3(blocks), dim3(T), lds, h->stream, h->B->d_tap,
-                           h->d_chist[h->csel] + (h->chist_len - hv), hv, h->n1, in0, h->n2, h->d_ataps, h->n_ataps, D,
-                           h->d_a2);
+        // matrix-core form when its tile fits LDS and the band is mostly taps (ntaps >= 4*D: at most ~4x padding)
+        int nw = 0;
+        if (!h->audio_valu && h->n_ataps >= 4 * D)
+            for (nw = 4; nw >= 1; nw >>= 1)
+                if (fir_mfma_lds_bytes(D, h->n_ataps, nw) <= 60 * 1024) break;
+        if (nw >= 1) {
+            const int TB = 256 * nw;
+            hipLaunchKernelGGL(k_fir_fff_mfma, dim3((unsigned)((h->n2 + TB - 1) / TB)), dim3(64 * nw),
+                               fir_mfma_lds_bytes(D, h->n_ataps, nw), h->stream, h->B->d_tap,
+                               h->d_chist[h->csel] + (h->chist_len - hv), hv, h->n1, in0, h->n2, h->d_ataps,
+                               h->n_ataps, D, h->d_a2);
+        } else {
+            const int T = 256;
+            size_t lds = ((size_t)(T - 1) * D + h->n_ataps) * sizeof(float);
+            int blocks = (int)((h->n2 + T - 1) / T);
+            hipLaunchKernelGGL(k_fir_fff_decim, dim3(blocks), dim3(T), lds, h->stream, h->B->d_tap,
+                               h->d_chist[h->csel] + (h->chist_len - hv), hv, h->n1, in0, h->n2, h->d_ataps,
+                               h->n_ataps, D, h->d_a2);
+        }
         FMCHK(h, hipGetLastError());
     }
     rc = fm_hist_update(h, h->d_chist, h->csel, h->chist_len, h->B->d_tap, h->n1);
@@ -279,7 +294,7 @@ extern "C" int sdr_fm_process(sdr_fm* h, const void* iq, size_t n, int is_dev, s
         FmDeemphState* st_out = h->d_deemph + (h->dsel ^ 1);
         if (warm <= 2048) {
             long long chunks = (h->n2 + DEEMPH_CHUNK - 1) / DEEMPH_CHUNK;
-            hipLaunchKernelGGL(k_deemph_warm, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, h->stream, h->d_a2,
+            hipLaunchKernelGGL(k_deemph_warm, dim3((unsigned)((chunks + 255) / 256)), dim3(256), deemph_lds_bytes(warm), h->stream, h->d_a2,
                                h->n2, h->b0, h->p1, warm, h->d_a3, st_in, st_out);
         } else
             hipLaunchKernelGGL(k_deemph, dim3(1), dim3(DEEMPH_THREADS), 0, h->stream, h->d_a2, h->n2, h->b0, h->p1,

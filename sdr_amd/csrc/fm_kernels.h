@@ -25,14 +25,33 @@ __global__ void __launch_bounds__(256) k_fir_fff_decim(const float* __restrict__
     const long long o0 = (long long)blockIdx.x * T;
     const long long lo = in0 + o0 * D - (ntaps - 1);
     const int count = (T - 1) * D + ntaps;
-    for (int i = threadIdx.x; i < count; i += T) {
-        long long idx = lo + i;
-        float s = 0.f;
-        if (idx >= 0) {
-            if (idx < n_in) s = v[idx];
-        } else if (hist && idx >= -(long long)hist_len)
-            s = hist[hist_len + idx];
-        lds[i] = s;
+    if (lo >= 0 && lo + count <= n_in) {
+        // interior tile (uniform test): eight unguarded loads in flight per lane before the first LDS store
+        // (one guarded load -> store per round was a chain of ~count/T load latencies per workgroup)
+        const float* __restrict__ src = v + lo;
+        for (int b = 0; b < count; b += 8 * T) {
+            float r[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int i = b + k * T + threadIdx.x;
+                r[k] = (i < count) ? src[i] : 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int i = b + k * T + threadIdx.x;
+                if (i < count) lds[i] = r[k];
+            }
+        }
+    } else {
+        for (int i = threadIdx.x; i < count; i += T) {
+            long long idx = lo + i;
+            float s = 0.f;
+            if (idx >= 0) {
+                if (idx < n_in) s = v[idx];
+            } else if (hist && idx >= -(long long)hist_len)
+                s = hist[hist_len + idx];
+            lds[i] = s;
+        }
     }
     __syncthreads();
     const long long o = o0 + threadIdx.x;
@@ -42,6 +61,155 @@ __global__ void __launch_bounds__(256) k_fir_fff_decim(const float* __restrict__
 #pragma unroll 8
     for (int j = 0; j < ntaps; ++j) a = __builtin_fmaf(rtaps[j], p[j], a);
     out[o] = a;
+}
+
+// The same filter on the f32 matrix cores (v_mfma_f32_16x16x4_f32: an fmaf chain in k order, bit-identical
+// to the loop above), as a banded Toeplitz product like k_frontend_mfma but real-valued:
+//   Y[i][G] = sum_k A[i][k] B[k][G],  A[i][k] = rtaps[k - i*D] (0 outside),  B[k][G] = x[16*D*G + k]
+// = output 16*G + i of the tile.  The wfm audio filter is ~771 taps at decimation 10: 771 LDS reads per output
+// on the vector ALUs (LDS-bound, 0.148 ms for 1.7 M outputs) against (771 + 150)/4 K-steps of one MFMA each.
+// blockDim.x = 64*nw; tile = 256*nw outputs.  Samples sit in LDS with 4 pad floats after every 16*D (lane
+// stride 16*D + 4 floats = 4 * odd: the 16 groups x 4 k-lanes of a B read hit 64 different banks).
+// Dynamic LDS: fir_mfma_lds_bytes(D, ntaps, nw).
+#define FIR_MFMA_INFLIGHT 12
+static inline size_t fir_mfma_lds_bytes(int D, int ntaps, int nw)
+{
+    const long long TB = 256LL * nw, BK = 16LL * D;
+    const long long ksteps = (15LL * D + ntaps + 3) >> 2;
+    const long long ntl = (15LL * D + 4 * (ksteps + 8) + 3) & ~3LL;
+    const long long npos = (TB - 1) * D + ntaps + 40;
+    return (size_t)(ntl + npos + 4 * (npos / BK + 2)) * sizeof(float);
+}
+__global__ void __launch_bounds__(256) k_fir_fff_mfma(const float* __restrict__ v, const float* __restrict__ hist,
+                                                      int hist_len, long long n_in, long long in0, long long nout,
+                                                      const float* __restrict__ rtaps, int ntaps, int D,
+                                                      float* __restrict__ out)
+{
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    float* const ldsf = reinterpret_cast<float*>(smem_raw);
+    const int T = blockDim.x, nw = T >> 6, TB = nw * 256;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int BK = 16 * D;
+    const long long o0 = (long long)blockIdx.x * TB;
+    const long long lo = in0 + o0 * D - (ntaps - 1);       // first input sample of the tile
+    const int ksteps = (15 * D + ntaps + 3) >> 2;
+    const int ntl = (15 * D + 4 * (ksteps + 8) + 3) & ~3;
+    const int npos = (TB - 1) * D + ntaps + 40;            // + K rounding and operand-prefetch slack
+    float* const smp = ldsf + ntl;
+
+    for (int i = t; i < ntl; i += T) {
+        const int idx = i - 15 * D;
+        ldsf[i] = (idx >= 0 && idx < ntaps) ? rtaps[idx] : 0.f;
+    }
+    {
+        // position p (sample lo + p) -> smp[p + 4*(p / BK)].  Interior tiles: aligned 16-B loads from the four
+        // samples' boundary below lo, up to FIR_MFMA_INFLIGHT per lane in flight before the first is used (the
+        // staging is a latency chain, not a bandwidth one: 4-B loads eight at a time took six round trips per
+        // tile and 3/4 of the kernel); the pad quotient stepped, not divided.
+        const int odd = (int)(lo & 3);
+        const long long lo_al = lo - odd;
+        const int nch = (npos + odd + 3) >> 2;
+        const bool interior = lo_al >= 0 && lo_al + 4LL * nch <= n_in && (reinterpret_cast<uintptr_t>(v) & 15) == 0;
+        if (interior) {
+            const float4* __restrict__ src4 = reinterpret_cast<const float4*>(v + lo_al);
+            int quo = (4 * t) / BK, rem = 4 * t - quo * BK;          // of 4c, c = this lane's chunk
+            const int dq = (4 * T) / BK, dr = 4 * T - dq * BK;
+            for (int b = 0; b < nch; b += FIR_MFMA_INFLIGHT * T) {
+                float4 r[FIR_MFMA_INFLIGHT];
+#pragma unroll
+                for (int k = 0; k < FIR_MFMA_INFLIGHT; ++k) {
+                    const int c = b + k * T + t;
+                    r[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (c < nch) r[k] = src4[c];
+                }
+#pragma unroll
+                for (int k = 0; k < FIR_MFMA_INFLIGHT; ++k) {
+                    const int c = b + k * T + t;
+                    if (c < nch) {
+                        const float e4[4] = {r[k].x, r[k].y, r[k].z, r[k].w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int pe = 4 * c + e - odd, re = rem + e - odd;
+                            const int qe = quo + (re >= BK ? 1 : 0) - (re < 0 ? 1 : 0);
+                            if (pe >= 0 && pe < npos) smp[pe + 4 * qe] = e4[e];
+                        }
+                    }
+                    quo += dq;
+                    rem += dr;
+                    if (rem >= BK) {
+                        rem -= BK;
+                        ++quo;
+                    }
+                }
+            }
+        } else {
+            // tiles at the ends of the call (history before v[0], zeros past the end), unaligned buffers
+            int quo = t / BK, rem = t - quo * BK;
+            const int dq = T / BK, dr = T - dq * BK;
+            for (int p = t; p < npos; p += T) {
+                const long long idx = lo + p;
+                float s = 0.f;
+                if (idx >= 0) {
+                    if (idx < n_in) s = v[idx];
+                } else if (hist && idx >= -(long long)hist_len)
+                    s = hist[hist_len + idx];
+                smp[p + 4 * quo] = s;
+                quo += dq;
+                rem += dr;
+                if (rem >= BK) {
+                    rem -= BK;
+                    ++quo;
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    {
+        const int g = lane & 15, kq = lane >> 4;
+        const int G = wave * 16 + g;
+        const float* ta = ldsf + (15 * D + kq - D * g);    // A[i = g][k]: tap index k - g*D, k = 4*kk + kq
+        const float* sb = smp + (BK + 4) * G + kq;         // B[k][col = g]: sample 16*D*G + k
+        const int ngrp = ksteps >> 2, tail = ksteps & 3;
+        int gi = 0;
+        float a[4], an[4], b[4], bn[4];
+        auto load = [&](float* av, float* bv) {
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                av[s4] = ta[4 * s4];
+                bv[s4] = sb[4 * s4];
+            }
+            ta += 16;
+            sb += 16;
+            if (++gi == D) {                               // 16*D samples done: step over the pad
+                gi = 0;
+                sb += 4;
+            }
+        };
+        load(a, b);
+        for (int grp = 0; grp < ngrp; ++grp) {
+            load(an, bn);                                  // next group's operands while this group's MFMAs run
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s4], b[s4], acc, 0, 0, 0);
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                a[s4] = an[s4];
+                b[s4] = bn[s4];
+            }
+        }
+#pragma unroll
+        for (int s4 = 0; s4 < 3; ++s4)
+            if (s4 < tail) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s4], b[s4], acc, 0, 0, 0);
+    }
+    // D[row = 4*(lane>>4) + r][col = lane&15] = output 16*col + row of this wave's 256: four consecutive per lane
+    const long long o = o0 + wave * 256 + 16 * (lane & 15) + 4 * (lane >> 4);
+    if (o + 4 <= nout)
+        *reinterpret_cast<float4*>(out + o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    else
+        for (int r = 0; r < 4; ++r)
+            if (o + r < nout) out[o + r] = acc[r];
 }
 
 // fm_deemph: y[n] = b0 x[n] + b0 x[n-1] + p1 y[n-1] with double accumulators
@@ -116,36 +284,72 @@ __global__ void __launch_bounds__(DEEMPH_THREADS) k_deemph(const float* __restri
 // Streaming: a chunk whose warm-up would reach before x[0] starts at x[0] from the EXACT state the
 // previous call left (st_in; zeros at stream start), the owner of the last sample leaves the state for
 // the next call in st_out (a different slot: other workgroups may still be reading st_in).
+// A workgroup owns 256 consecutive chunks.  Its inputs (own span + warm-up + the sample before) are staged
+// into LDS by coalesced loads and its outputs leave through LDS the same way: a thread walking global
+// memory one float at a time paid one load latency per step (warm + 16 dependent steps: 0.047 ms for
+// 1.7 M samples).  One pad float per 16 keeps the lanes' stride-16 walks on distinct banks.
+// Dynamic LDS: deemph_lds_bytes(warm).
+#define DEEMPH_PAD(j) ((j) + ((j) >> 4))
+static inline size_t deemph_lds_bytes(int warm)
+{
+    const int span = 256 * DEEMPH_CHUNK, nst = span + warm + 1;
+    return (size_t)(DEEMPH_PAD(nst) + 1 + DEEMPH_PAD(span) + 1) * sizeof(float);
+}
 __global__ void __launch_bounds__(256) k_deemph_warm(const float* __restrict__ x, long long n, double b0, double p1,
                                                      int warm, float* __restrict__ y,
                                                      const FmDeemphState* __restrict__ st_in,
                                                      FmDeemphState* __restrict__ st_out)
 {
-    const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long a0 = c * DEEMPH_CHUNK;
-    if (a0 >= n) return;
-    const long long a1 = (a0 + DEEMPH_CHUNK < n) ? a0 + DEEMPH_CHUNK : n;
-    long long i = a0 - warm;
-    double yp = 0.0, xp;
-    if (i <= 0) {
-        i = 0;
-        yp = st_in->yp;
-        xp = st_in->xp;
-    } else
-        xp = (double)x[i - 1];
-    for (; i < a1; ++i) {
-        double xi = (double)x[i];
-        double acc = b0 * xi;
-        acc += b0 * xp;
-        acc += p1 * yp;
-        xp = xi;
-        yp = acc;
-        if (i >= a0) y[i] = (float)acc;
+    extern __shared__ float dl[];
+    const int span = 256 * DEEMPH_CHUNK, nst = span + warm + 1;
+    const long long B0 = (long long)blockIdx.x * span;
+    const long long g0 = B0 - warm - 1;                    // sample index of staged position 0
+    float* const yo = dl + DEEMPH_PAD(nst) + 1;
+    for (int j = threadIdx.x; j < nst; j += 256) {
+        const long long g = g0 + j;
+        dl[DEEMPH_PAD(j)] = (g >= 0 && g < n) ? x[g] : 0.f;
     }
-    if (a1 == n) {
-        st_out->xp = xp;
-        st_out->yp = yp;
+    __syncthreads();
+    const long long a0 = B0 + (long long)threadIdx.x * DEEMPH_CHUNK;
+    if (a0 < n) {
+        const long long a1 = (a0 + DEEMPH_CHUNK < n) ? a0 + DEEMPH_CHUNK : n;
+        long long i = a0 - warm;
+        double yp = 0.0, xp;
+        if (i <= 0) {
+            i = 0;
+            yp = st_in->yp;
+            xp = st_in->xp;
+        } else {
+            const int jp = (int)(i - 1 - g0);
+            xp = (double)dl[DEEMPH_PAD(jp)];
+        }
+        int j = (int)(i - g0);
+        for (; i < a0; ++i, ++j) {
+            const double xi = (double)dl[DEEMPH_PAD(j)];
+            double acc = b0 * xi;
+            acc += b0 * xp;
+            acc += p1 * yp;
+            xp = xi;
+            yp = acc;
+        }
+        int o = threadIdx.x * DEEMPH_CHUNK;
+        for (; i < a1; ++i, ++j, ++o) {
+            const double xi = (double)dl[DEEMPH_PAD(j)];
+            double acc = b0 * xi;
+            acc += b0 * xp;
+            acc += p1 * yp;
+            xp = xi;
+            yp = acc;
+            yo[DEEMPH_PAD(o)] = (float)acc;
+        }
+        if (a1 == n) {
+            st_out->xp = xp;
+            st_out->yp = yp;
+        }
     }
+    __syncthreads();
+    for (int j = threadIdx.x; j < span; j += 256)
+        if (B0 + j < n) y[B0 + j] = yo[DEEMPH_PAD(j)];
 }
 
 // rational_resampler_fff: output m = sum_k h[p + k L] x[i - k], p = (m M) mod L,

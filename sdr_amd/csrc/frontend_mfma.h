@@ -130,6 +130,7 @@ __device__ __forceinline__ void slice_tile_xn(const bool* valid, const float* v,
     }
 }
 
+#define MFMA_ROT_K 4   // 16-B loads in flight per lane in the rotating staging loop (8: 145 VGPRs, 3 waves per SIMD)
 // blockDim.x = 64*nw, P.tile_out = 256*nw - q.  Dynamic LDS: tap table | padded samples (aliased by the output tile).
 __global__ void __launch_bounds__(256) k_frontend_mfma(FrontParams P)
 {
@@ -172,6 +173,9 @@ __global__ void __launch_bounds__(256) k_frontend_mfma(FrontParams P)
     int odd = (int)(gidx & 1);
     const long long lo_al = lo_idx - odd;
     const int nsrc = (npos + odd + 1) >> 1;                // 16-B source chunks
+#if defined(MFMA_ABL) && MFMA_ABL == 1
+    if (P.n < 0)
+#endif
     if (P.vec_ok && !P.pre_tab) {
         // chunks inside the capture by DMA; the few that touch its edges (zero
         // padding / streaming history) by guarded loads of their own lanes
@@ -199,16 +203,82 @@ __global__ void __launch_bounds__(256) k_frontend_mfma(FrontParams P)
                 }
             }
         }
-    } else {
-        odd = 0;
-        for (int p = t; p < npos; p += T) {
-            const long long idx = lo_idx + p;
-            float2 v = fetch(idx);
-            if (P.pre_tab) {
-                const float2 r = nco_eval(P.pre_tab, (P.pre_idx0 + (unsigned long long)idx) * P.pre_inc);
-                v = make_float2(__builtin_fmaf(v.x, r.x, -(v.y * r.y)), __builtin_fmaf(v.x, r.y, v.y * r.x));
+    } else if (P.vec_ok) {
+        // The FM chain's first stage rotates every input sample on the way in (freq_xlating_fir_filter with
+        // taps = [1] ahead of the resampler), so its tile goes through registers: 16-B loads, MFMA_ROT_K in flight
+        // per lane before the first is used (one load -> rotate -> store per round made the staging a chain of
+        // ~17 global-load latencies per workgroup: 0.33 ms for 2^26 samples), NCO phase by 64-bit adds
+        // (phase = index * inc mod 2^64 exactly), the padded LDS position by a stepped quotient.
+        const int per8 = 8 * D;                            // source chunks per pad block
+        const bool interior = lo_al >= 0 && lo_al + 2LL * nsrc <= P.n;   // uniform
+        unsigned long long ph = (P.pre_idx0 + (unsigned long long)(lo_al + 2LL * t)) * P.pre_inc;
+        const unsigned long long dph = P.pre_inc * (unsigned long long)(2 * T);
+        int quo = t / per8, rem = t - quo * per8;
+        const int dq = T / per8, dr = T - dq * per8;
+        const float4* __restrict__ x4 = reinterpret_cast<const float4*>(x + lo_al);
+        for (int c0 = 0; c0 < nsrc; c0 += MFMA_ROT_K * T) {
+            float4 rg[MFMA_ROT_K];
+#pragma unroll
+            for (int k = 0; k < MFMA_ROT_K; ++k) {
+                const int sc = c0 + k * T + t;
+                rg[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (sc < nsrc) {
+                    if (interior)
+                        rg[k] = x4[sc];
+                    else {
+                        const float2 a = fetch(lo_al + 2LL * sc), b = fetch(lo_al + 2LL * sc + 1);
+                        rg[k] = make_float4(a.x, a.y, b.x, b.y);
+                    }
+                }
             }
-            *reinterpret_cast<float2*>(smp + 2 * p + 4 * (p / BK)) = v;
+#pragma unroll
+            for (int k = 0; k < MFMA_ROT_K; ++k) {
+                const int sc = c0 + k * T + t;
+                if (sc < nsrc) {
+                    const float2 r0 = nco_eval(P.pre_tab, ph), r1 = nco_eval(P.pre_tab, ph + P.pre_inc);
+                    float4 v;
+                    v.x = __builtin_fmaf(rg[k].x, r0.x, -(rg[k].y * r0.y));
+                    v.y = __builtin_fmaf(rg[k].x, r0.y, rg[k].y * r0.x);
+                    v.z = __builtin_fmaf(rg[k].z, r1.x, -(rg[k].w * r1.y));
+                    v.w = __builtin_fmaf(rg[k].z, r1.y, rg[k].w * r1.x);
+                    *reinterpret_cast<float4*>(smp + 4 * (sc + quo)) = v;
+                }
+                ph += dph;
+                quo += dq;
+                rem += dr;
+                if (rem >= per8) {
+                    rem -= per8;
+                    ++quo;
+                }
+            }
+        }
+    } else {
+        // Register staging: unaligned buffers, and the FM chain's first stage, which rotates every input
+        // sample on the way in (freq_xlating_fir_filter with taps = [1] ahead of the resampler).  Per
+        // sample: one unguarded 8-B load on interior tiles (uniform test), the NCO phase by a 64-bit ADD
+        // (phase = index * inc mod 2^64 exactly: one multiply per thread, then + inc*T per round), the
+        // pad position p / BK by a stepped quotient instead of a division per sample.
+        odd = 0;
+        const bool rot = P.pre_tab != nullptr;
+        unsigned long long ph = rot ? (P.pre_idx0 + (unsigned long long)(lo_idx + t)) * P.pre_inc : 0ull;
+        const unsigned long long dph = P.pre_inc * (unsigned long long)T;
+        int quo = t / BK, rem = t - quo * BK;
+        const int dq = T / BK, dr = T - dq * BK;
+        const bool interior = lo_idx >= 0 && lo_idx + npos <= P.n;   // uniform
+        for (int p = t; p < npos; p += T) {
+            float2 v = interior ? x[lo_idx + p] : fetch(lo_idx + p);
+            if (rot) {
+                const float2 r = nco_eval(P.pre_tab, ph);
+                v = make_float2(__builtin_fmaf(v.x, r.x, -(v.y * r.y)), __builtin_fmaf(v.x, r.y, v.y * r.x));
+                ph += dph;
+            }
+            *reinterpret_cast<float2*>(smp + 2 * p + 4 * quo) = v;
+            quo += dq;
+            rem += dr;
+            if (rem >= BK) {
+                rem -= BK;
+                ++quo;
+            }
         }
     }
     __syncthreads();
@@ -243,7 +313,11 @@ __global__ void __launch_bounds__(256) k_frontend_mfma(FrontParams P)
             }
         };
         load(a, b);
+#if defined(MFMA_ABL) && MFMA_ABL == 2
+        for (int grp = 0; grp < (P.n < 0 ? ngrp : 0); ++grp) {
+#else
         for (int grp = 0; grp < ngrp; ++grp) {
+#endif
             load(an, bn);  // operands of the next group are fetched while this group's 8 MFMAs run
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4) {
@@ -263,6 +337,9 @@ __global__ void __launch_bounds__(256) k_frontend_mfma(FrontParams P)
                 accI = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s4], b[s4].y, accI, 0, 0, 0);
             }
     }
+#if defined(MFMA_ABL) && MFMA_ABL == 3
+    if (P.n > 0 && accR[0] != 12345.f) return;
+#endif
     __syncthreads();  // every wave is done with the samples: the output tile aliases them
     float2* const ybuf = reinterpret_cast<float2*>(smp);
     {

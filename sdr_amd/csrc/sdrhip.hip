@@ -428,7 +428,8 @@ static bool pick_mfma(const sdr_handle* h, int& T, size_t& lds)
     if (h->front_mode == 1 || h->front_mode == 3 || h->rt_complex || h->in_fmt != SDR_IN_FC32) return false;
     const int D = h->cfg.decim, nt = h->ntaps;
     if (h->front_mode == 0 && 4.0 * nt / D < 24.0) return false;
-    for (int nw = 4; nw >= 1; nw >>= 1) {
+    const int nw0 = (h->tile_override == 64 || h->tile_override == 128) ? h->tile_override / 64 : 4;   // tuning override
+    for (int nw = nw0; nw >= 1; nw >>= 1) {
         size_t b = mfma_lds_bytes(D, nt, nw);
         if (b) {
             T = 64 * nw;

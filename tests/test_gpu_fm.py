@@ -61,3 +61,18 @@ def test_fm_chain_streaming_chunks_equal_one_shot():
         one = r.fetch(4)
         _cmp(one, got[4], exact=False)
         assert float(np.max(np.abs(one - got[4]))) <= 1e-6 * float(np.max(np.abs(one)))
+
+
+def test_fm_audio_fir_vector_form(monkeypatch):
+    """The audio FIR has two forms (matrix cores; vector ALUs when the tile does not fit LDS or the filter is
+    short): force the second (SDR_FM_AUDIO=valu, read at create) and hold it to the same bits."""
+    fs, n = 2e6, 300000
+    iq = synth.fm_iq(n, fs, f_off=200e3, seed=5)
+    want = odsp.fm_radio_chain(iq, samp_rate=fs, shift=200e3, volume=0.8)
+    monkeypatch.setenv("SDR_FM_AUDIO", "valu")
+    with fm.FmRadio(samp_rate=fs, shift=200e3, volume=0.8, max_samples=n) as r:
+        r.process(iq[:123457])
+        a = r.fetch(2)
+        r.process(iq[123457:])
+        got = np.concatenate([a, r.fetch(2)])
+    _cmp(got, want[2], exact=True)

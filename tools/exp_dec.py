@@ -1,0 +1,30 @@
+"""Scratch: front-end kernel time of one decimating shape under SDR_FRONTEND=mfma|valu|auto.
+usage: exp_dec.py ntaps decim demod(mag2|quad) ncap log2n [modes...]"""
+import os, sys, numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from sdr_amd import chain
+if len(sys.argv) < 6:
+    sys.argv = [sys.argv[0]] + os.environ.get("DEC_ARGS", "131 4 mag2 1 26 mfma valu").split()
+nt, D, demod, ncap, lg = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], int(sys.argv[4]), int(sys.argv[5])
+n = 1 << lg
+dev = torch.device("cuda", 0)
+g = torch.Generator(device=dev); g.manual_seed(1)
+iq = 0.3 * torch.randn((ncap, n, 2), generator=g, device=dev, dtype=torch.float32)
+rng = np.random.default_rng(nt)
+taps = (rng.standard_normal(nt) / nt ** 0.5).astype(np.float32)
+for mode in sys.argv[6:] or ["mfma", "valu"]:
+    os.environ["SDR_FRONTEND"] = mode
+    c = chain.Chain(2e6, decim=D, taps=taps, demod=chain.DEMOD_QUAD if demod == "quad" else chain.DEMOD_MAG2,
+                    thr=(-0.2, 0.2) if demod == "quad" else (0.05, 0.15), keep_n=1, max_batch=ncap, max_frames=4, max_samples=n)
+    c.set_stream(torch.cuda.current_stream().cuda_stream)
+    for _ in range(3):
+        c.batch_process(iq)
+    torch.cuda.synchronize()
+    c.profile_enable(True)
+    for _ in range(20):
+        c.batch_process(iq)
+    torch.cuda.synchronize()
+    f, b = c.profile_read()
+    ms = float(np.mean(f))
+    print("%-5s ntaps %3d /%d %s: front %.4f ms  %.1f Gsps in  %.1f TF  %.0f GB/s" % (mode, nt, D, demod, ms, ncap * n / ms / 1e6, 4.0 * nt * ncap * n / D / ms / 1e9, 8.0 * ncap * n / ms / 1e6), flush=True)
+    c.close()
