@@ -301,9 +301,14 @@ SDR_API size_t sdr_static_scratch_bytes(void);
  * count as the zeros before stream start).  The threshold_ff state is unknown at
  * that point: it restarts from cfg.thr_init, and sdr_segment_info afterwards says
  * which leading bytes of the NEXT sdr_process_iq call depended on it.  Decoder
- * state, rawBuffer and squelch/post-filter state are reset; chains with a
- * prefilter, a squelch or a post-demod filter are refused (their state is not
- * a function of the halo alone). */
+ * state and rawBuffer are reset.
+ * A chain with more than one memory -- a prefilter stage (mumbi/FS300.grc:3157-3242),
+ * a post-demod filter (TFA/analyzer2.grc:3151-3232) -- is positioned by running it
+ * over the halo from empty memories: every stage is FIR, so its state at abs_index
+ * is a function of the last sdr_history_len(h) samples, which for these chains is
+ * the sum of the stages' spans in input samples (a few thousand) instead of the
+ * channel filter's history.  A squelch chain is refused: its power average is an
+ * IIR and its gate makes output positions data dependent. */
 SDR_API int sdr_history_len(sdr_handle* h);
 SDR_API int sdr_seek(sdr_handle* h, uint64_t abs_index, const void* halo, size_t n_halo, int is_device_ptr);
 typedef struct sdr_segment_info {

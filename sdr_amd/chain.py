@@ -249,6 +249,8 @@ class Chain(object):
 
     # -- one long capture in segments (sdr_seek / sdr_segment_info_get)
     def history_len(self):
+        """Input samples in front of a segment that seek() needs: the channel filter's history, or -- for a
+        chain with a prefilter stage or a post-demod filter -- the sum of the stages' spans."""
         return int(self._L.sdr_history_len(self._h))
 
     def seek(self, abs_index, halo=None):

@@ -1542,13 +1542,80 @@ extern "C" int sdr_export_frames(sdr_handle* h, void* frames_dev, size_t frames_
 }
 
 // ------------------------------------------------------------------ segments
-extern "C" int sdr_history_len(sdr_handle* h) { return h ? h->hist_len : SDR_E_ARG; }
+// A chain with more than one memory (prefilter stage, post-demod filter, rotated input) is positioned by
+// running it over the halo: its state at abs_index depends on the last seek_span() input samples only
+// (every stage is FIR), so a chain started `span` samples early from empty memories has, at abs_index, the
+// state of the stream from sample 0.
+static bool seek_by_warmup(const sdr_handle* h) { return h->pre || h->cfg.post_ntaps > 0 || h->prerotate; }
+static long long seek_span(const sdr_handle* h)
+{
+    const long long D = h->cfg.decim;
+    // hist_len covers the channel filter and the discriminator's previous output; each of the post filter's
+    // post_ntaps-1 remembered outputs is D inputs further back; + one decimation period of alignment
+    long long L = h->hist_len + (h->cfg.post_ntaps > 0 ? (long long)h->cfg.post_ntaps * D : 0) + D;
+    if (h->pre) L = h->pre->hist_len + (L + 1) * h->pre->cfg.decim;
+    return L;
+}
+
+extern "C" int sdr_history_len(sdr_handle* h)
+{
+    if (!h) return SDR_E_ARG;
+    return seek_by_warmup(h) ? (int)seek_span(h) : h->hist_len;
+}
+
+static int seek_warm(sdr_handle* h, uint64_t abs_index, const void* halo, size_t n_halo, int is_dev)
+{
+    const unsigned long long L = (unsigned long long)seek_span(h);
+    const size_t need = (size_t)(abs_index < L ? abs_index : L);
+    if (n_halo < need || (need && !halo))
+        return fail(h, SDR_E_ARG, "sdr_seek: halo shorter than min(abs_index, sdr_history_len)");
+    (void)hipSetDevice(h->device);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    // every stage at absolute index a0 = abs_index - need with empty memories
+    const unsigned long long a0 = abs_index - need;
+    unsigned long long a_main = a0;
+    if (sdr_handle* p = h->pre) {
+        for (int i = 0; i < 2; ++i) HIPCHK(h, hipMemsetAsync(p->d_hist[i], 0, (size_t)p->hist_cap * sizeof(float2), h->stream));
+        p->in_count = a0;
+        p->out_count = a0 / (unsigned long long)p->cfg.decim;
+        p->keep_ctr = 1;
+        a_main = p->out_count;
+    }
+    for (int i = 0; i < 2; ++i) {
+        HIPCHK(h, hipMemsetAsync(h->d_hist[i], 0, (size_t)h->hist_cap * sizeof(float2), h->stream));
+        if (h->d_post_hist[i])
+            HIPCHK(h, hipMemsetAsync(h->d_post_hist[i], 0, (size_t)(h->cfg.post_ntaps + 1) * sizeof(float), h->stream));
+    }
+    const unsigned long long D = (unsigned long long)h->cfg.decim, kn = (unsigned long long)h->cfg.keep_n;
+    h->in_count = a_main;
+    h->out_count = a_main / D;
+    h->keep_ctr = (long long)(kn - (h->out_count % kn));
+    h->raw_n = 0;
+    int r = reset_dec_state(h);
+    if (r) return r;
+    // warm-up over the halo; what it emits (bits, frames, decoder state) is discarded below
+    const sdr_handle* first = h->pre ? h->pre : h;
+    const size_t ss = first->ss(), chunk = (size_t)first->cfg.max_samples;
+    const char* src = (const char*)halo + (n_halo - need) * ss;
+    for (size_t off = 0; off < need; off += chunk) {
+        const size_t k = need - off < chunk ? need - off : chunk;
+        r = sdr_process_iq(h, src + off * ss, k, is_dev, nullptr);
+        if (r) return r;
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->raw_n = 0;
+    h->last_ncap = 0;
+    h->last_nb = h->last_nout = h->last_bits_off = 0;
+    return reset_dec_state(h);
+}
 
 extern "C" int sdr_seek(sdr_handle* h, uint64_t abs_index, const void* halo, size_t n_halo, int is_dev)
 {
     if (!h) return fail(h, SDR_E_ARG, "sdr_seek: null handle");
-    if (h->pre || h->squelch_on || h->cfg.post_ntaps > 0 || h->prerotate)
-        return fail(h, SDR_E_ARG, "sdr_seek: chains with a prefilter, squelch or post-demod filter cannot be positioned from a halo");
+    if (h->squelch_on)
+        return fail(h, SDR_E_ARG, "sdr_seek: a squelch chain cannot be positioned from a halo (the power average is an IIR "
+                                  "and the gate makes output positions data dependent)");
+    if (seek_by_warmup(h)) return seek_warm(h, abs_index, halo, n_halo, is_dev);
     const size_t H = (size_t)h->hist_len;
     const size_t need = abs_index < H ? (size_t)abs_index : H;
     if (n_halo < need || (need && !halo))

@@ -110,6 +110,66 @@ def test_segments_quad_demod_and_decode():
     assert np.array_equal(segments.stitch_segments(pb, infos, 0), one_bits)
 
 
+def test_segments_of_multi_stage_chains():
+    """Chains with more than one memory are positioned by a warm-up over a longer halo (sdr_history_len grows
+    accordingly): the mumbi FS300 two-filter graph (mumbi/FS300.grc:3157-3242: 97-tap LPF -> 329-tap 1/10
+    resampler -> mag^2 -> keep 1-in-20) and the TFA analyzer2 graph (TFA/analyzer2.grc:3151-3232: rotate +500 kHz
+    -> mag^2 -> 7-tap float LPF) cut into ragged segments: floats and stitched bytes == the oracle's one pass."""
+    from tests.test_gpu_chain import _assert_float_parity
+    fs = 2e6
+    rng = np.random.default_rng(78)
+    # --- prefilter + decimating second stage
+    sym = synth.mumbi_symbols(bytes([0x12, 0x34, 0x56, 0x78, 0x80]), repeats=4)
+    iq = synth.ook_iq(synth.envelope(sym, fs, lead_in_us=9000.0), fs, amp=0.9, sigma=0.02, rng=rng)
+    n = iq.size
+    lpf = chain.low_pass(1.0, fs, 100e3, 50e3)
+    rs = chain.resampler_taps(1, 10)
+    wv = odsp.mag2(odsp.fir_ccf(odsp.fir_ccf(iq, lpf, 1), rs, 10))[:n // 10]
+    wb, _, _ = odsp.slice_bits(wv, 1.0, 0.1, 0.4, 20)
+    cuts = [0, 1237, 1240, 50001, n // 2 + 3, n - 777, n]
+    with chain.Chain(fs, pre_taps=lpf, pre_decim=1, decim=10, taps=rs, demod=chain.DEMOD_MAG2, thr=(0.1, 0.4),
+                     keep_n=20, tap_demod=True, max_samples=n) as c:
+        H = c.history_len()
+        assert H >= 96 + 328 + 10
+        with pytest.raises(_lib_err()):
+            c.seek(100000, iq[100000 - H + 1:100000])      # one sample short
+        # segments in REVERSE order on one handle: nothing may leak from one seek to the next
+        res = {}
+        for a, b in reversed(list(zip(cuts[:-1], cuts[1:]))):
+            info = segments.run_segment(c, iq, a, b)
+            res[a] = (info, c.fetch_bits().copy(), c.fetch_demod().copy())
+    order = sorted(res)
+    assert _assert_float_parity(np.concatenate([res[a][2] for a in order]), wv) == 0
+    got = segments.stitch_segments([res[a][1] for a in order], [res[a][0] for a in order], 0)
+    assert np.array_equal(got, wb[:got.size]) and got.size == wb.size and wb.sum() > 50
+    # --- post-demod float filter behind a rotated input
+    sym = []
+    for _ in range(2):
+        pk = synth.tfa_packet(ident=int(rng.integers(0, 65536)), temp_c=21.5, humidity=int(rng.integers(0, 100)))
+        sym += synth.tfa_symbols(synth.tfa_bits(pk), rng, reset_gap_us=900.0)
+    env = np.concatenate([synth.envelope(sym, fs, lead_in_us=800.0), np.zeros(2500, np.uint8)])
+    iq = synth.ook_iq(env, fs, f_off=500e3, amp=0.9, sigma=0.01, rng=rng)
+    n = iq.size
+    post = chain.low_pass(1.0, fs, 500e3, 1e6, chain.WIN_BLACKMAN)
+    wv = odsp.fir_fff(odsp.mag2(odsp.freq_xlating_fir(iq, [1.0], 500e3, fs, 1)), post, 1)
+    wb, _, _ = odsp.slice_bits(wv, 1.0, 0.2, 0.4, 1)
+    bounds = [(0, 5), (5, 6), (6, 4099), (4099, n // 2), (n // 2, n)]
+    with chain.Chain(fs, decim=1, center_freq=500e3, demod=chain.DEMOD_MAG2, thr=(0.2, 0.4), keep_n=1, post_taps=post,
+                     tap_demod=True, max_samples=n) as c:
+        infos, bits, vs = [], [], []
+        for a, b in bounds:
+            infos.append(segments.run_segment(c, iq, a, b))
+            bits.append(c.fetch_bits().copy())
+            vs.append(c.fetch_demod().copy())
+    assert _assert_float_parity(np.concatenate(vs), wv) == 0
+    assert np.array_equal(segments.stitch_segments(bits, infos, 0), wb) and wb.sum() > 1000
+
+
+def _lib_err():
+    from sdr_amd import _lib
+    return _lib.SdrError
+
+
 def test_seek_argument_checks():
     from sdr_amd import _lib
     with chain.Chain(FS, decim=10, taps=_taps(), max_samples=4096) as c:

@@ -14,8 +14,9 @@ rng = np.random.default_rng(nt)
 taps = (rng.standard_normal(nt) / nt ** 0.5).astype(np.float32)
 for mode in sys.argv[6:] or ["mfma", "valu"]:
     os.environ["SDR_FRONTEND"] = mode
-    c = chain.Chain(2e6, decim=D, taps=taps, demod=chain.DEMOD_QUAD if demod == "quad" else chain.DEMOD_MAG2,
-                    thr=(-0.2, 0.2) if demod == "quad" else (0.05, 0.15), keep_n=1, max_batch=ncap, max_frames=4, max_samples=n)
+    c = chain.Chain(2e6, decim=D, taps=taps, demod={"quad": chain.DEMOD_QUAD, "mag2": chain.DEMOD_MAG2, "none": chain.DEMOD_NONE}[demod],
+                    thr=(-0.2, 0.2) if demod == "quad" else (0.05, 0.15), keep_n=1, max_batch=ncap, max_frames=4, max_samples=n,
+                    tap_demod=(demod == "none"), center_freq=float(os.environ.get("DEC_FC", "0")))
     c.set_stream(torch.cuda.current_stream().cuda_stream)
     for _ in range(3):
         c.batch_process(iq)
