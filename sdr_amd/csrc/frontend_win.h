@@ -29,12 +29,86 @@ __host__ __device__ inline int win_sample_slots(int T, int ntaps)
     return T * WIN_R + ((ntaps + 1 + WIN_W - 1) / WIN_W) * WIN_W + WIN_W + 2;
 }
 
+typedef float win_v2f __attribute__((ext_vector_type(2)));
+
+// Epilogue of one tile.  FULL: every output of the tile exists and is emitted (but tile index 0 of a
+// discriminator tile, which is the previous tile's last output), keep_n == 1, no float tap.
+template <bool FULL>
+__device__ __forceinline__ void win_epilogue(const FrontParams& P, const int tile, const int cap, win_v2f* acc,
+                                             const long long m_t0, const int i_lo, const int i_hi, const int q, int* sh,
+                                             const float* s_atan, float2* s_edge, unsigned char* pack)
+{
+    constexpr int R = WIN_R;
+    typedef win_v2f v2f;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const long long m0 = m_t0 + (long long)R * t;
+    bool valid[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int i = R * t + r;
+        if (FULL)
+            valid[r] = r > 0 || i >= q;
+        else {
+            if (!(i >= i_lo && i < i_hi)) acc[r] = (v2f){0.f, 0.f};
+            valid[r] = i >= q && i < i_hi;
+        }
+    }
+    if (P.demod == SDR_DEMOD_NONE) {
+        if (P.tap) {
+            float2* dst = reinterpret_cast<float2*>(P.tap + (long long)cap * P.tap_stride);
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if (valid[r]) dst[m0 + r] = make_float2(acc[r].x, acc[r].y);
+        }
+        return;
+    }
+    float v[R];
+    if (P.demod == SDR_DEMOD_MAG2) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) v[r] = __builtin_fmaf(acc[r].x, acc[r].x, acc[r].y * acc[r].y);
+    } else {
+        // the output before the thread's first one belongs to the neighbouring lane (wave)
+        float2 pv;
+        pv.x = __shfl_up(acc[R - 1].x, 1);
+        pv.y = __shfl_up(acc[R - 1].y, 1);
+        if (lane == 63) s_edge[wave] = make_float2(acc[R - 1].x, acc[R - 1].y);
+        __syncthreads();
+        if (lane == 0) pv = wave ? s_edge[wave - 1] : make_float2(0.f, 0.f);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            // computed for every lane and output (no exec-masked block per output); outputs that do not
+            // exist have zero accumulators, the ones not emitted are dropped by valid[] below
+            const float2 pr = r ? make_float2(acc[r - 1].x, acc[r - 1].y) : pv;
+            const float tr = __builtin_fmaf(acc[r].x, pr.x, acc[r].y * pr.y);
+            const float ti = __builtin_fmaf(acc[r].y, pr.x, -(acc[r].x * pr.y));
+#if defined(WIN_ABL) && WIN_ABL == 2
+            const float a = ti + tr;
+#else
+            const float a = fast_atan2f_dev(s_atan, ti, tr);
+#endif
+            v[r] = valid[r] ? a : 0.f;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) v[r] = P.gain * v[r];
+    if (P.tap) {
+        float* dst = P.tap + (long long)cap * P.tap_stride;
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            if (valid[r]) dst[m0 + r] = v[r];
+    }
+    if (!P.do_slice) return;
+    slice_tile_xn<R, FULL>(valid, v, R * t, m_t0, P.lo, P.hi, P.keep_n, P.keep_c0, P.bits + (long long)cap * P.bits_stride,
+                           P.tsum + (long long)cap * P.tiles_per_capture + tile, sh, pack);
+}
+
+
 // One tile: blockDim.x = T (64 or 256) threads, T*WIN_R - q outputs.
 __device__ __forceinline__ void win_tile(const FrontParams& P, const int tile, const int cap, unsigned char* smem_raw,
                                          int* sh, const float* s_atan, float2* s_edge)
 {
     constexpr int R = WIN_R, W = WIN_W;
-    const int T = blockDim.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int T = blockDim.x, t = threadIdx.x, lane = t & 63;
     const int nt = P.ntaps, H = nt - 1;
     const int q = (P.demod == SDR_DEMOD_QUAD) ? 1 : 0;
     const int ntl = win_tap_floats(nt);
@@ -111,7 +185,7 @@ __device__ __forceinline__ void win_tile(const FrontParams& P, const int tile, c
     // component, the same rounding as two fmaf calls) so that the tap can be taken from either half of
     // its register pair by op_sel -- the compiler's own selection moved every odd tap and every window
     // pair into fresh registers first (94 moves per 156 fmas).
-    typedef float v2f __attribute__((ext_vector_type(2)));
+    typedef win_v2f v2f;
     typedef float v4f __attribute__((ext_vector_type(4)));
     v2f acc[R];
 #pragma unroll
@@ -169,64 +243,16 @@ __device__ __forceinline__ void win_tile(const FrontParams& P, const int tile, c
     // ---- epilogue: thread t owns outputs R*t .. R*t+R-1 of the tile (tile-relative index i: FIR output
     // m_t0 + i).  An output exists for i in [i_lo, i_hi) (m >= 0 or streaming history, m < nout) and is
     // emitted for i in [q, i_hi): uniform 32-bit limits instead of 64-bit compares per lane and output.
-    const long long m0 = m_t0 + (long long)R * t;
     const long long left = P.nout - m_t0;
     const int i_hi = left > (long long)T * R ? T * R : (left < 0 ? 0 : (int)left);
     const int i_lo = (P.hist != nullptr || m_t0 >= 0) ? 0 : (int)(-m_t0);
-    bool valid[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const int i = R * t + r;
-        if (!(i >= i_lo && i < i_hi)) acc[r] = (v2f){0.f, 0.f};
-        valid[r] = i >= q && i < i_hi;
-    }
-    if (P.demod == SDR_DEMOD_NONE) {
-        if (P.tap) {
-            float2* dst = reinterpret_cast<float2*>(P.tap + (long long)cap * P.tap_stride);
-#pragma unroll
-            for (int r = 0; r < R; ++r)
-                if (valid[r]) dst[m0 + r] = make_float2(acc[r].x, acc[r].y);
-        }
-        return;
-    }
-    float v[R];
-    if (P.demod == SDR_DEMOD_MAG2) {
-#pragma unroll
-        for (int r = 0; r < R; ++r) v[r] = __builtin_fmaf(acc[r].x, acc[r].x, acc[r].y * acc[r].y);
-    } else {
-        // the output before the thread's first one belongs to the neighbouring lane (wave)
-        float2 pv;
-        pv.x = __shfl_up(acc[R - 1].x, 1);
-        pv.y = __shfl_up(acc[R - 1].y, 1);
-        if (lane == 63) s_edge[wave] = make_float2(acc[R - 1].x, acc[R - 1].y);
-        __syncthreads();
-        if (lane == 0) pv = wave ? s_edge[wave - 1] : make_float2(0.f, 0.f);
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            // computed for every lane and output (no exec-masked block per output); outputs that do not
-            // exist have zero accumulators, the ones not emitted are dropped by valid[] below
-            const float2 pr = r ? make_float2(acc[r - 1].x, acc[r - 1].y) : pv;
-            const float tr = __builtin_fmaf(acc[r].x, pr.x, acc[r].y * pr.y);
-            const float ti = __builtin_fmaf(acc[r].y, pr.x, -(acc[r].x * pr.y));
-#if defined(WIN_ABL) && WIN_ABL == 2
-            const float a = ti + tr;
-#else
-            const float a = fast_atan2f_dev(s_atan, ti, tr);
-#endif
-            v[r] = valid[r] ? a : 0.f;
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < R; ++r) v[r] = P.gain * v[r];
-    if (P.tap) {
-        float* dst = P.tap + (long long)cap * P.tap_stride;
-#pragma unroll
-        for (int r = 0; r < R; ++r)
-            if (valid[r]) dst[m0 + r] = v[r];
-    }
-    if (!P.do_slice) return;
-    slice_tile_xn<R>(valid, v, R * t, m_t0, P.lo, P.hi, P.keep_n, P.keep_c0, P.bits + (long long)cap * P.bits_stride,
-                     P.tsum + (long long)cap * P.tiles_per_capture + tile, sh);
+    // interior tile of a slicing chain that keeps every byte: no per-output masks, packed byte stores
+    const bool full = i_lo == 0 && i_hi == T * R && P.do_slice && !P.tap && P.keep_n == 1 && m_t0 - P.keep_c0 >= 0 &&
+                      P.demod != SDR_DEMOD_NONE;
+    if (full)
+        win_epilogue<true>(P, tile, cap, acc, m_t0, i_lo, i_hi, q, sh, s_atan, s_edge, reinterpret_cast<unsigned char*>(lds));
+    else
+        win_epilogue<false>(P, tile, cap, acc, m_t0, i_lo, i_hi, q, sh, s_atan, s_edge, nullptr);
 }
 
 // blockDim.x = T (64 or 256), P.D == 1, real taps, P.tile_out = T*WIN_R - q; one tile per workgroup.
