@@ -6,7 +6,13 @@ cannot be imported under this image's Python 3.10; this file follows them
 statement by statement with the three changes SURVEY.md section 8c lists:
 ``//`` for the histogram index, explicit ragged-``np.split`` handling with the
 2017-numpy ``.size``/``.shape[0]`` semantics, Python-int field maths (numpy-1
-scalar promotion).  ``np.histogram(..., "auto")`` is numpy 2.2.6's.
+scalar promotion).  ``np.histogram(..., "auto")`` is numpy 2.2.6's.  One place
+where that choice matters: widths whose inter-quartile range is 0 (a packet of
+mostly one symbol).  numpy >= 1.15 then bins by the Sturges width alone; the
+numpy the Python-2 reference ran (< 1.15) made ONE bin, so ``edges[size // 2]``
+was the longest width.  The reference holds no vector with IQR == 0, so that
+case is PARITY UNPINNED; the modern behaviour is what is restated
+(tests/test_host_decode.py::test_hist_auto_with_zero_iqr_is_numpy_2).
 
 Pinned by the reference's known-answer vectors (tests/golden/kat.json,
 tests/test_oracle_kat.py): TS33C README pulses/gaps -> packet/fields, the two

@@ -43,6 +43,43 @@ def test_hist_auto_mid_edge_matches_numpy(L):
         assert _mid_edge(L, x) == e[e.size // 2], x
 
 
+def test_hist_auto_with_zero_iqr_is_numpy_2(L):
+    """np.histogram(x, "auto") when the middle half of the widths is one value (IQR == 0; plausible at 20 kHz,
+    where widths are multiples of 50 us and a packet can be mostly one symbol).  The oracle and the library
+    reproduce numpy >= 1.15 (here 2.2.6): the Freedman-Diaconis width is 0, so the Sturges width alone sets the
+    bins.  The reference is Python 2 and ran an older numpy, where a zero "auto" width meant ONE bin and
+    edges[size // 2] was the maximum -- a different pulse_short_limit.  Nothing in the reference pins either
+    (its README packet has IQR > 0): this case is parity unpinned, and the test states which behaviour is built."""
+    cases = [np.array([400.0] * 50 + [900.0] * 14), np.array([450.0] * 60 + [950.0] * 7),
+             np.array([400.0] * 81 + [900.0] * 3 + [950.0] * 2), np.array([500.0] * 9 + [1000.0])]
+    for x in cases:
+        q75, q25 = np.percentile(x, [75, 25])
+        assert q75 - q25 == 0.0
+        e = np.histogram(x, "auto")[1]
+        assert _mid_edge(L, x) == e[e.size // 2]
+        assert e.size > 2 and x.min() < e[e.size // 2] < x.max()      # not the single-bin edge of numpy < 1.15
+
+
+def test_ts33c_packet_of_mostly_one_symbol(L):
+    """The decoder-level form of the case above: 81 short pulses and 9 long ones (two widths among the long
+    ones).  Library (host-compiled device code) == oracle, limit between the classes; under the one-bin rule
+    the limit would be the longest pulse and the 900 us pulses would flip to 1."""
+    sym = synth.ts33c_symbols([1] * 81 + [0] * 9, None)
+    k = [i for i, (lvl, w) in enumerate(sym) if lvl == 1 and w > 700.0]
+    sym[k[0]] = (1, sym[k[0]][1] + 50.0)                            # one long pulse a sample longer
+    env = np.concatenate([synth.envelope(sym, 20000, lead_in_us=3000.0), np.zeros(100, np.uint8)]).astype(np.int8)
+    o = dec.TS33CStreamDecoder(sample_rate=20000)
+    o.work([env])
+    g = HostDec(L, _lib.DEC_TS33C, 20000)
+    g.work(env)
+    assert len(o.frames) == len(g.frames) == 1
+    assert_ts33c_equal(o.frames[0], g.frames[0])
+    lim = o.frames[0]["pulse_short_limit"]
+    assert 450.0 < lim < 900.0 and o.frames[0]["nbits"] == 90
+    assert o.frames[0]["packet"] == bytes(9) + b"\xff"
+    g.close()
+
+
 def test_pow_tables_match_numpy(L):
     """n**(-1/3) and log2(n) feed the bin width; the library tabulates them with
     libm on the host -- must equal what numpy computes on this host."""
