@@ -1,4 +1,5 @@
-// Channel filter at decimation 1 with real taps (fir_filter_ccf as the reference wires it:
+// Channel filter at decimation 1, real taps or the complex band-pass taps of freq_xlating_fir_filter_ccc
+// (win_tile<true>: two packed fmas per tap, the NCO in the epilogue) (fir_filter_ccf as the reference wires it:
 // TFA/decoder.grc:1163-1234 27 taps, FM-Radio/FM-Radio.grc:674-746 33 taps, TS33C/live_decoder.grc:917-988
 // 121 taps) on the vector ALUs with a SLIDING WINDOW: every lane owns WIN_R consecutive outputs and
 // keeps the samples they share in registers, so one LDS read feeds WIN_R packed fmas instead of one.
@@ -22,7 +23,7 @@
 #define WIN_W 16
 
 // LDS floats of the tap table (shifted copy + one block of slack), 16-B multiple
-__host__ __device__ inline int win_tap_floats(int ntaps) { return (ntaps + 1 + WIN_W + 3) & ~3; }
+__host__ __device__ inline int win_tap_floats(int ntaps, bool cplx = false) { return ((ntaps + 1 + WIN_W + 3) & ~3) * (cplx ? 2 : 1); }
 // staged sample positions: T*R outputs + taps rounded up to whole blocks + one block of look-ahead
 __host__ __device__ inline int win_sample_slots(int T, int ntaps)
 {
@@ -51,6 +52,16 @@ __device__ __forceinline__ void win_epilogue(const FrontParams& P, const int til
         else {
             if (!(i >= i_lo && i < i_hi)) acc[r] = (v2f){0.f, 0.f};
             valid[r] = i >= q && i < i_hi;
+        }
+    }
+    if (P.nco_tab) {   // freq_xlating_fir_filter_ccc: complex band-pass taps in front, the output rotated (uniform)
+        unsigned long long ph = (P.nco_m0 + (unsigned long long)m0) * P.nco_inc;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const float2 rot = nco_eval(P.nco_tab, ph);
+            const v2f y = acc[r];
+            acc[r] = (v2f){__builtin_fmaf(y.x, rot.x, -(y.y * rot.y)), __builtin_fmaf(y.x, rot.y, y.y * rot.x)};
+            ph += P.nco_inc;
         }
     }
     if (P.demod == SDR_DEMOD_NONE) {
@@ -104,6 +115,10 @@ __device__ __forceinline__ void win_epilogue(const FrontParams& P, const int til
 
 
 // One tile: blockDim.x = T (64 or 256) threads, T*WIN_R - q outputs.
+// CPLX: complex taps (rtaps = interleaved re,im): per tap and output two packed fmas in the oracle's order,
+//   (re, im) += a * (x.re, x.im);   (re, im) += (-b, b) * (x.im, x.re)        tap = a + jb
+// the halves of the tap pair and the swapped sample picked by op_sel, the sign by neg_lo: no extra moves.
+template <bool CPLX>
 __device__ __forceinline__ void win_tile(const FrontParams& P, const int tile, const int cap, unsigned char* smem_raw,
                                          int* sh, const float* s_atan, float2* s_edge)
 {
@@ -111,7 +126,7 @@ __device__ __forceinline__ void win_tile(const FrontParams& P, const int tile, c
     const int T = blockDim.x, t = threadIdx.x, lane = t & 63;
     const int nt = P.ntaps, H = nt - 1;
     const int q = (P.demod == SDR_DEMOD_QUAD) ? 1 : 0;
-    const int ntl = win_tap_floats(nt);
+    const int ntl = win_tap_floats(nt, CPLX);
     float* const tapL = reinterpret_cast<float*>(smem_raw);
     float2* const lds = reinterpret_cast<float2*>(tapL + ntl);
 
@@ -172,9 +187,18 @@ __device__ __forceinline__ void win_tile(const FrontParams& P, const int tile, c
     }
     // tap table, shifted by one when the tile starts odd: tapL[j] = rtaps[j - shift]
     const int shift = lsh & 1;
-    for (int i = t; i < ntl; i += T) {
-        const int idx = i - shift;
-        tapL[i] = (idx >= 0 && idx < nt) ? P.rtaps[idx] : 0.f;
+    if (CPLX) {
+        float2* const tapC = reinterpret_cast<float2*>(tapL);
+        const float2* __restrict__ rt2 = reinterpret_cast<const float2*>(P.rtaps);
+        for (int i = t; i < (ntl >> 1); i += T) {
+            const int idx = i - shift;
+            tapC[i] = (idx >= 0 && idx < nt) ? rt2[idx] : make_float2(0.f, 0.f);
+        }
+    } else {
+        for (int i = t; i < ntl; i += T) {
+            const int idx = i - shift;
+            tapL[i] = (idx >= 0 && idx < nt) ? P.rtaps[idx] : 0.f;
+        }
     }
     __syncthreads();
 #if defined(WIN_ABL) && WIN_ABL == 4
@@ -203,16 +227,18 @@ __device__ __forceinline__ void win_tile(const FrontParams& P, const int tile, c
         }
 #define WIN_FMA_LO(A, TP, X) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(A) : "v"(TP), "v"(X))
 #define WIN_FMA_HI(A, TP, X) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(A) : "v"(TP), "v"(X))
+// complex tap TP = (a, b): second step, (lo, hi) += (-b * x.hi, b * x.lo)
+#define WIN_CFMA_B(A, TP, X) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "+v"(A) : "v"(TP), "v"(X))
 #if defined(WIN_ABL) && WIN_ABL == 1
         for (int r = 0; r < R; ++r) acc[r] = w[r];
         for (int j0 = 0; j0 < 0; j0 += W) {
 #else
         for (int j0 = 0; j0 < jhi; j0 += W) {
 #endif
-            v2f tp[W / 2];   // tap pairs (t[2k], t[2k+1])
+            v2f tp[CPLX ? W : W / 2];   // real: tap pairs (t[2k], t[2k+1]); complex: one (re, im) per tap
 #pragma unroll
-            for (int k = 0; k < W / 4; ++k) {
-                const v4f v = pt[(j0 >> 2) + k];
+            for (int k = 0; k < (CPLX ? W / 2 : W / 4); ++k) {
+                const v4f v = pt[(CPLX ? (j0 >> 1) : (j0 >> 2)) + k];
                 tp[2 * k] = v.xy;
                 tp[2 * k + 1] = v.zw;
             }
@@ -221,12 +247,19 @@ __device__ __forceinline__ void win_tile(const FrontParams& P, const int tile, c
 #pragma unroll
             for (int u = 0; u < W; ++u) {
                 if (full || (j0 + u >= jlo && j0 + u < jhi)) {
+                    if (CPLX) {
 #pragma unroll
-                    for (int r = 0; r < R; ++r) {
-                        if (u & 1)
-                            WIN_FMA_HI(acc[r], tp[u >> 1], w[(u + r) % W]);
-                        else
-                            WIN_FMA_LO(acc[r], tp[u >> 1], w[(u + r) % W]);
+                        for (int r = 0; r < R; ++r) WIN_FMA_LO(acc[r], tp[CPLX ? u : 0], w[(u + r) % W]);
+#pragma unroll
+                        for (int r = 0; r < R; ++r) WIN_CFMA_B(acc[r], tp[CPLX ? u : 0], w[(u + r) % W]);
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < R; ++r) {
+                            if (u & 1)
+                                WIN_FMA_HI(acc[r], tp[u >> 1], w[(u + r) % W]);
+                            else
+                                WIN_FMA_LO(acc[r], tp[u >> 1], w[(u + r) % W]);
+                        }
                     }
                 }
                 if (u & 1) {
@@ -238,6 +271,7 @@ __device__ __forceinline__ void win_tile(const FrontParams& P, const int tile, c
         }
 #undef WIN_FMA_LO
 #undef WIN_FMA_HI
+#undef WIN_CFMA_B
     }
 
     // ---- epilogue: thread t owns outputs R*t .. R*t+R-1 of the tile (tile-relative index i: FIR output
@@ -259,6 +293,7 @@ __device__ __forceinline__ void win_tile(const FrontParams& P, const int tile, c
 // (A workgroup walking 2..16 consecutive tiles was measured and dropped: no faster at any count -- the
 // kernel is bound by its VALU instruction count, not by workgroup dispatch -- and the loop-carried
 // values cost 40 VGPRs, i.e. two resident waves per SIMD.)
+template <bool CPLX>
 __global__ void __launch_bounds__(256) k_frontend_win(FrontParams P)
 {
     extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -267,5 +302,5 @@ __global__ void __launch_bounds__(256) k_frontend_win(FrontParams P)
     __shared__ float2 s_edge[4];
     if (P.demod == SDR_DEMOD_QUAD)
         for (int i = threadIdx.x; i < 257; i += blockDim.x) s_atan[i] = P.atan_tab[i];
-    win_tile(P, blockIdx.x, blockIdx.y, smem_raw, sh, s_atan, s_edge);
+    win_tile<CPLX>(P, blockIdx.x, blockIdx.y, smem_raw, sh, s_atan, s_edge);
 }

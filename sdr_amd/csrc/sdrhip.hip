@@ -411,15 +411,15 @@ static size_t mfma_lds_bytes(int D, int ntaps, int nw)
 
 // The matrix-core kernel pays when the filter is fp32-FMA bound: real taps and
 // enough flops per input sample that the LDS-walking kernel is not HBM bound.
-// k_frontend_win (frontend_win.h): decimation 1, real taps, complex64 input.  Every lane owns WIN_R
+// k_frontend_win (frontend_win.h): decimation 1, real or complex (xlating) taps, complex64 input.  Every lane owns WIN_R
 // consecutive outputs; chosen over the matrix-core form there (measured).
 static bool pick_win(const sdr_handle* h, long long nout, int& T, size_t& lds)
 {
-    if (h->front_mode == 1 || h->front_mode == 2 || h->rt_complex || h->in_fmt != SDR_IN_FC32 || h->cfg.decim != 1) return false;
+    if (h->front_mode == 1 || h->front_mode == 2 || h->in_fmt != SDR_IN_FC32 || h->cfg.decim != 1 || h->prerotate) return false;
     if (h->front_mode == 0 && h->ntaps < 8) return false;
     T = nout >= 8LL * 256 * WIN_R ? 256 : 64;
     if (h->tile_override == 64 || h->tile_override == 128 || h->tile_override == 256) T = h->tile_override;
-    lds = (size_t)win_tap_floats(h->ntaps) * 4 + (size_t)win_sample_slots(T, h->ntaps) * sizeof(float2);
+    lds = (size_t)win_tap_floats(h->ntaps, h->rt_complex) * 4 + (size_t)win_sample_slots(T, h->ntaps) * sizeof(float2);
     return lds <= 60 * 1024;
 }
 
@@ -843,8 +843,10 @@ static int launch_front(sdr_handle* h, const float2* x, long long stride, long l
     } else if (c.demod == SDR_DEMOD_NONE && !h->d_tap)
         return fail(h, SDR_E_ARG, "demod NONE needs cfg.tap_demod (complex output buffer)");
     dim3 grid(g.tiles, ncap), block(g.T);
-    if (g.win)
-        hipLaunchKernelGGL(k_frontend_win, grid, block, g.lds, h->stream, P);
+    if (g.win && P.taps_complex)
+        hipLaunchKernelGGL(k_frontend_win<true>, grid, block, g.lds, h->stream, P);
+    else if (g.win)
+        hipLaunchKernelGGL(k_frontend_win<false>, grid, block, g.lds, h->stream, P);
     else if (g.mfma)
         hipLaunchKernelGGL(k_frontend_mfma, grid, block, g.lds, h->stream, P);
     else if (h->in_fmt == SDR_IN_CU8 && P.vec_ok && !P.pre_tab && P.ktaps_n > 0 && g.use_lds && !h->no_raw8) {

@@ -1,4 +1,4 @@
-"""The sliding-window channel filter (k_frontend_win: decimation 1, real taps, 10 outputs per lane) must
+"""The sliding-window channel filter (k_frontend_win: decimation 1, real or complex taps, 10 outputs per lane) must
 equal the oracle and the one-output-per-lane kernel word for word: same fmaf chain, oldest sample first.
 SDR_FRONTEND (read by sdr_create) forces a kernel."""
 import ctypes as C
@@ -99,3 +99,65 @@ def test_win_nonfinite_sample_stays_local():
         bad = ~np.isfinite(y[1])
         assert bad.sum() == min(taps.size, n - pos) and bad[pos:pos + taps.size].all()
         assert np.isfinite(y[0]).all()
+
+
+@pytest.mark.parametrize("ntaps,fc", [(1, 250e3), (2, -100e3), (16, 37e3), (17, 100e3), (27, -500e3), (121, 100e3)])
+def test_win_xlating_complex_taps_bit_exact(ntaps, fc):
+    """freq_xlating_fir_filter_ccc at decimation 1 (complex band-pass taps, then the NCO): the window kernel's
+    complex-tap form against the one-output-per-lane kernel and the oracle, complex outputs word for word;
+    even and odd capture strides (aligned DMA staging with the shifted tap table / guarded staging)."""
+    from sdr_amd import _lib, chain
+    rng = np.random.default_rng(ntaps * 13 + 1)
+    taps = rng.standard_normal(ntaps).astype(np.float32) / np.float32(max(1, ntaps) ** 0.5)
+    fs = 1e6
+    for n, extra in ((30000 + 301, 0), (30000 + 301, 1), (777, 0), (3, 0)):
+        ncap = 3
+        st = n + 1 + extra
+        flat = _iq(ncap * st, ntaps + n) * np.float32(0.5)
+        got = {}
+        for mode in ("win", "valu"):
+            c = _chain(mode, fs, decim=1, center_freq=fc, taps=taps, demod=chain.DEMOD_NONE, tap_demod=True,
+                       max_batch=ncap, max_samples=n)
+            _lib.check(c._h, c._L.sdr_batch_process(c._h, C.c_void_p(flat.ctypes.data), n, st, ncap, 0, C.byref(c.out)))
+            got[mode] = c.fetch_demod().reshape(ncap, -1)
+            c.close()
+        assert _same_words(got["win"], got["valu"])
+        for i in range(ncap):
+            assert _same_words(got["win"][i], odsp.freq_xlating_fir(flat[i * st:i * st + n], taps, fc, fs, 1))
+
+
+@pytest.mark.parametrize("demod,keep_n", [("mag2", 1), ("mag2", 50), ("quad", 1), ("quad", 3)])
+def test_win_xlating_demod_slicer_and_streaming(demod, keep_n):
+    """The reference-wired TS33C graph with a carrier offset (shape R, xlating variant): 121
+    translated taps at decimation 1 -> demod -> threshold -> slicer -> keep 1-in-n; batch and ragged streaming
+    chunks, floats and bytes against the oracle blocks."""
+    from sdr_amd import chain
+    fs, fc = 1e6, 100e3
+    taps = odsp.low_pass(1.0, fs, 20e3, 40e3)
+    n = 50000 + 13
+    x = _iq(n, 77 + keep_n) * np.float32(0.4)
+    y = odsp.freq_xlating_fir(x, taps, fc, fs, 1)
+    gain = 2.0 if demod == "mag2" else 0.9
+    lo, hi = (0.05, 0.15) if demod == "mag2" else (-0.3, 0.3)
+    v = odsp.mag2(y) if demod == "mag2" else odsp.quad_demod(y, 1.0)
+    wb, _, _ = odsp.slice_bits(v, gain, lo, hi, keep_n)
+    dm = chain.DEMOD_MAG2 if demod == "mag2" else chain.DEMOD_QUAD
+    for tap in (True, False):                      # without the float tap interior tiles take the packed-store path
+        c = _chain("win", fs, decim=1, center_freq=fc, taps=taps, demod=dm, demod_gain=gain, thr=(lo, hi), keep_n=keep_n,
+                   tap_demod=tap, max_samples=n)
+        c.batch_process(x[None, :])
+        if tap:
+            assert _same_words(c.fetch_demod(), np.float32(gain) * v)
+        np.testing.assert_array_equal(c.fetch_bits(), wb)
+        c.close()
+    c = _chain("win", fs, decim=1, center_freq=fc, taps=taps, demod=dm, demod_gain=gain, thr=(lo, hi), keep_n=keep_n,
+               tap_demod=True, max_samples=n)
+    cuts = [0, 1, 2, 7, 2559, 2560, 2561, 9000, 9001, 40001, n]
+    fl, bi = [], []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        c.process_iq(x[a:b])
+        fl.append(c.fetch_demod())
+        bi.append(c.fetch_bits())
+    c.close()
+    assert _same_words(np.concatenate(fl), np.float32(gain) * v)
+    np.testing.assert_array_equal(np.concatenate(bi), wb)
