@@ -32,6 +32,7 @@ N_PER_CAPTURE = 1 << 18
 DECIM = 50
 F_OFF = 100e3
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32 vector peak = f32-input MFMA peak
 BYTES_PER_SAMPLE = 8.0 + 1.0 / DECIM  # complex64 in + sliced byte out
 
 
@@ -202,16 +203,23 @@ def fm_workload(torch, dev, skip_cpu, n=1 << 26, fs=2.4e6, steps=10):
     gpu_ms = float(np.mean([ev[k].elapsed_time(ev[k + 1]) for k in range(steps)]))
     bps = 8.0 + 4.0 * 48e3 / fs
     ach = bps * n / (gpu_ms * 1e-3) / 1e9
+    # algorithmic flops per input sample of the four FIRs (real taps on complex data = 4 flop per tap, on floats 2):
+    # 131-tap resampler /4, 33-tap LPF at fs/4, 771-tap audio filter /10 at fs/4, 821-tap 24/25 polyphase resampler
+    fps = 4.0 * 131 / 4 + 4.0 * 33 / 4 + 2.0 * 771 / 40 + 2.0 * (821 / 24.0) * (24.0 / 25.0) / 40
+    tf = fps * n / (gpu_ms * 1e-3) / 1e12
     out = {"value": round(n / dt / 1e6, 1), "unit": "Msps", "ms_per_step": round(dt * 1e3, 4), "samples": n,
            "sample_rate": fs, "audio_samples": int(na),
            "chain": "xlating->resample 1/4->lpf->quadrature_demod->audio fir /10->deemph 75us->resample 24/25 (streaming state carried)",
-           "roofline": {"bound": "hbm", "kernel": "whole chain: k_frontend_mfma (131 taps /4) + k_frontend_win (33 taps, discriminator) + "
-                        "k_fir_fff_decim + k_deemph_warm + k_resample_fff", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "kernel_ms": round(gpu_ms, 4),
+           "roofline": {"bound": "mfma", "kernel": "whole chain: k_frontend_mfma (rotate + 131 taps /4) + k_frontend_win (33 taps, "
+                        "discriminator) + k_fir_fff_mfma (771 taps /10) + k_deemph_warm + k_resample_fff",
+                        "achieved": round(tf, 1), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(tf / FP32_PEAK_TFLOPS, 4), "traffic": None, "kernel_ms": round(gpu_ms, 4),
+                        "flops_per_launch": fps * n, "hbm_achieved_gbs": round(ach, 1), "hbm_frac": round(ach / HBM_PEAK_GBS, 4),
                         "bytes_per_launch": bps * n,
-                        "note": "algorithmic bytes = 8 B in + 4 B * 48e3/fs out per input sample (SURVEY 8d); the stage outputs "
-                                "between the five kernels (2 + 1 B per input sample, written and re-read) are not counted; "
-                                "131 flop per input sample in the first stage alone puts the chain near the fp32 ridge"}}
+                        "note": "%.0f algorithmic flop per 8.08 algorithmic bytes (SURVEY 8d) is above the fp32 ridge (157.3 TF / "
+                                "8 TB/s = 19.7 flop/B): the chain is priced against the f32 FMA peak; hbm_frac is the same time "
+                                "against the HBM roofline.  The stage outputs between the five kernels (2 + 1 B per input "
+                                "sample, written and re-read) are not counted" % fps}}
     if not skip_cpu:
         from oracle import dsp as odsp
         want, reps, tc = timed_repeat(lambda: odsp.fm_radio_chain(iq, samp_rate=fs, shift=200e3), 2.0)
@@ -232,7 +240,6 @@ def fm_workload(torch, dev, skip_cpu, n=1 << 26, fs=2.4e6, steps=10):
     return out
 
 
-FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32 vector peak = f32-input MFMA peak
 
 
 def r_shape_workload(torch, dev, skip_cpu, ncap=64, n=1 << 19, fs=2e6, steps=20):

@@ -119,11 +119,7 @@ __device__ __forceinline__ void slice_tile_xn(const bool* valid, const float* v,
                 st = 1;
             else if (evt[e] == 2)
                 st = 0;
-#if defined(WIN_ABL) && WIN_ABL == 3
-            if (valid[e] && st == 77) pb[i0 + e] = (int8_t)st;
-#else
             if (valid[e]) pb[i0 + e] = (int8_t)st;
-#endif
         }
         return;
     }
@@ -205,9 +201,6 @@ __global__ void __launch_bounds__(256) k_frontend_mfma(FrontParams P)
     int odd = (int)(gidx & 1);
     const long long lo_al = lo_idx - odd;
     const int nsrc = (npos + odd + 1) >> 1;                // 16-B source chunks
-#if defined(MFMA_ABL) && MFMA_ABL == 1
-    if (P.n < 0)
-#endif
     if (P.vec_ok && !P.pre_tab) {
         // chunks inside the capture by DMA; the few that touch its edges (zero
         // padding / streaming history) by guarded loads of their own lanes
@@ -345,11 +338,7 @@ __global__ void __launch_bounds__(256) k_frontend_mfma(FrontParams P)
             }
         };
         load(a, b);
-#if defined(MFMA_ABL) && MFMA_ABL == 2
-        for (int grp = 0; grp < (P.n < 0 ? ngrp : 0); ++grp) {
-#else
         for (int grp = 0; grp < ngrp; ++grp) {
-#endif
             load(an, bn);  // operands of the next group are fetched while this group's 8 MFMAs run
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4) {
@@ -369,9 +358,6 @@ __global__ void __launch_bounds__(256) k_frontend_mfma(FrontParams P)
                 accI = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s4], b[s4].y, accI, 0, 0, 0);
             }
     }
-#if defined(MFMA_ABL) && MFMA_ABL == 3
-    if (P.n > 0 && accR[0] != 12345.f) return;
-#endif
     __syncthreads();  // every wave is done with the samples: the output tile aliases them
     float2* const ybuf = reinterpret_cast<float2*>(smp);
     {

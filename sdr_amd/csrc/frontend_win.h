@@ -27,7 +27,7 @@ __host__ __device__ inline int win_tap_floats(int ntaps, bool cplx = false) { re
 // staged sample positions: T*R outputs + taps rounded up to whole blocks + one block of look-ahead
 __host__ __device__ inline int win_sample_slots(int T, int ntaps)
 {
-    return T * WIN_R + ((ntaps + 1 + WIN_W - 1) / WIN_W) * WIN_W + WIN_W + 2;
+    return T * WIN_R + ((ntaps + 1 + WIN_W - 1) / WIN_W) * WIN_W + WIN_W + 2 + 8;   // + 8: cu8 tiles start on a 16-B chunk
 }
 
 typedef float win_v2f __attribute__((ext_vector_type(2)));
@@ -92,11 +92,7 @@ __device__ __forceinline__ void win_epilogue(const FrontParams& P, const int til
             const float2 pr = r ? make_float2(acc[r - 1].x, acc[r - 1].y) : pv;
             const float tr = __builtin_fmaf(acc[r].x, pr.x, acc[r].y * pr.y);
             const float ti = __builtin_fmaf(acc[r].y, pr.x, -(acc[r].x * pr.y));
-#if defined(WIN_ABL) && WIN_ABL == 2
-            const float a = ti + tr;
-#else
             const float a = fast_atan2f_dev(s_atan, ti, tr);
-#endif
             v[r] = valid[r] ? a : 0.f;
         }
     }
@@ -142,7 +138,56 @@ __device__ __forceinline__ void win_tile(const FrontParams& P, const int tile, c
         return make_float2(0.f, 0.f);
     };
     int lsh = 0;   // LDS index of sample lo_idx
-    if (P.vec_ok && !P.pre_tab) {
+    if (P.in_fmt == SDR_IN_CU8) {
+        // rtl-sdr bytes ((u8 - 127.4) / 128 per component, the oracle's two exact ops): converted on the way in.
+        // Interior tiles of an aligned buffer: 16-B chunks of eight samples from the chunk boundary below the
+        // tile, four 16-B LDS writes each; edge tiles and unaligned buffers sample by sample.
+        const uchar2* __restrict__ xb = reinterpret_cast<const uchar2*>(P.x) + (long long)cap * P.stride;
+        auto fetch8 = [&](long long idx) -> float2 {
+            uchar2 u;
+            if (idx >= 0) {
+                if (idx >= P.n) return make_float2(0.f, 0.f);
+                u = xb[idx];
+            } else if (P.hist && idx >= -(long long)P.hist_len)
+                u = reinterpret_cast<const uchar2*>(P.hist)[P.hist_len + idx];
+            else
+                return make_float2(0.f, 0.f);
+            return cu8_to_f2(u.x, u.y);
+        };
+        const long long gidx = (long long)cap * P.stride + lo_idx;
+        const int s8 = P.vec_ok ? (int)(gidx & 7) : 0;
+        const long long lo_al = lo_idx - s8;
+        const int nch = (count + s8 + 7) >> 3;
+        lsh = s8;
+        if (P.vec_ok && lo_al >= 0 && lo_al + 8LL * nch <= P.n) {   // uniform
+            const uint4* __restrict__ src = reinterpret_cast<const uint4*>(xb + lo_al);
+            for (int c0 = 0; c0 < nch; c0 += 2 * T) {
+                uint4 rg[2];
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int c = c0 + k * T + t;
+                    rg[k] = make_uint4(0u, 0u, 0u, 0u);
+                    if (c < nch) rg[k] = src[c];
+                }
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int c = c0 + k * T + t;
+                    if (c < nch) {
+                        const unsigned wd[4] = {rg[k].x, rg[k].y, rg[k].z, rg[k].w};
+                        float4* dst = reinterpret_cast<float4*>(lds + 8 * c);
+#pragma unroll
+                        for (int d = 0; d < 4; ++d) {   // one dword = two samples (I, Q, I, Q)
+                            const float2 a = cu8_to_f2((unsigned char)(wd[d] & 0xffu), (unsigned char)((wd[d] >> 8) & 0xffu));
+                            const float2 b = cu8_to_f2((unsigned char)((wd[d] >> 16) & 0xffu), (unsigned char)(wd[d] >> 24));
+                            dst[d] = make_float4(a.x, a.y, b.x, b.y);
+                        }
+                    }
+                }
+            }
+        } else {
+            for (int i = t; i < count + s8; i += T) lds[i] = fetch8(lo_al + i);
+        }
+    } else if (P.vec_ok && !P.pre_tab) {
         // 16-B chunks inside the capture by DMA (a loop that holds nothing else), the few that touch
         // its edges by guarded loads -- as k_frontend
         const long long gidx = (long long)cap * P.stride + lo_idx;
@@ -201,9 +246,6 @@ __device__ __forceinline__ void win_tile(const FrontParams& P, const int tile, c
         }
     }
     __syncthreads();
-#if defined(WIN_ABL) && WIN_ABL == 4
-    if (P.ntaps > 0) return;
-#endif
 
     // ---- sliding-window FIR.  The packed fmas are written out (v_pk_fma_f32: one IEEE fma per
     // component, the same rounding as two fmaf calls) so that the tap can be taken from either half of
@@ -229,12 +271,7 @@ __device__ __forceinline__ void win_tile(const FrontParams& P, const int tile, c
 #define WIN_FMA_HI(A, TP, X) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(A) : "v"(TP), "v"(X))
 // complex tap TP = (a, b): second step, (lo, hi) += (-b * x.hi, b * x.lo)
 #define WIN_CFMA_B(A, TP, X) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "+v"(A) : "v"(TP), "v"(X))
-#if defined(WIN_ABL) && WIN_ABL == 1
-        for (int r = 0; r < R; ++r) acc[r] = w[r];
-        for (int j0 = 0; j0 < 0; j0 += W) {
-#else
         for (int j0 = 0; j0 < jhi; j0 += W) {
-#endif
             v2f tp[CPLX ? W : W / 2];   // real: tap pairs (t[2k], t[2k+1]); complex: one (re, im) per tap
 #pragma unroll
             for (int k = 0; k < (CPLX ? W / 2 : W / 4); ++k) {

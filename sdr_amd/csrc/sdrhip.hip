@@ -411,11 +411,11 @@ static size_t mfma_lds_bytes(int D, int ntaps, int nw)
 
 // The matrix-core kernel pays when the filter is fp32-FMA bound: real taps and
 // enough flops per input sample that the LDS-walking kernel is not HBM bound.
-// k_frontend_win (frontend_win.h): decimation 1, real or complex (xlating) taps, complex64 input.  Every lane owns WIN_R
+// k_frontend_win (frontend_win.h): decimation 1, real or complex (xlating) taps, complex64 or cu8 input.  Every lane owns WIN_R
 // consecutive outputs; chosen over the matrix-core form there (measured).
 static bool pick_win(const sdr_handle* h, long long nout, int& T, size_t& lds)
 {
-    if (h->front_mode == 1 || h->front_mode == 2 || h->in_fmt != SDR_IN_FC32 || h->cfg.decim != 1 || h->prerotate) return false;
+    if (h->front_mode == 1 || h->front_mode == 2 || h->cfg.decim != 1 || h->prerotate) return false;
     if (h->front_mode == 0 && h->ntaps < 8) return false;
     T = nout >= 8LL * 256 * WIN_R ? 256 : 64;
     if (h->tile_override == 64 || h->tile_override == 128 || h->tile_override == 256) T = h->tile_override;

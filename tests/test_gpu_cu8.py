@@ -93,3 +93,49 @@ def test_cu8_prefilter_chain_takes_bytes():
         y = c.fetch_demod()
     want = odsp.fir_ccf(odsp.fir_ccf(odsp.cu8_to_fc32(u), lp, 1), rs, 10)
     assert np.array_equal(y.view(np.uint32), want.view(np.uint32))
+
+
+@pytest.mark.parametrize("fc", [0.0, 100e3])
+@pytest.mark.parametrize("n,ncap,pad", [(30000 + 301, 3, 0), (30000 + 301, 3, 3), (8000, 2, 8), (100, 1, 0)])
+def test_cu8_reference_wiring_on_the_window_kernel(fc, n, ncap, pad):
+    """A recorded .cu8 file through the reference's own graph (TS33C/live_decoder.grc:917-988: 121 taps at
+    decimation 1, keep 1-in-50 after the slicer), with and without a carrier offset: the sliding-window kernel
+    converts the bytes while staging -- 16-B chunks on aligned rows (pad 0, 8: row strides of whole chunks,
+    tiles that start anywhere inside a chunk), sample by sample otherwise (pad 3).  Floats and bytes against the
+    oracle on the converted samples; streaming in ragged chunks on top."""
+    from tests.test_gpu_mfma import _chain
+    import ctypes as C
+    from sdr_amd import _lib
+    rng = np.random.default_rng(n + ncap + pad)
+    st = ((n + 7) // 8) * 8 + pad
+    flat = rng.integers(100, 156, (ncap * st, 2), dtype=np.uint8)
+    taps = chain.low_pass(1.0, FS, 20e3, 40e3)
+    res = {}
+    for mode in ("win", "valu"):
+        c = _chain(mode, FS, decim=1, center_freq=fc, taps=taps, demod=chain.DEMOD_MAG2, demod_gain=8.0, thr=(0.05, 0.15),
+                   keep_n=50, tap_demod=True, max_batch=ncap, max_samples=n, input_format="cu8")
+        _lib.check(c._h, c._L.sdr_batch_process(c._h, C.c_void_p(flat.ctypes.data), n, st, ncap, 0, C.byref(c.out)))
+        res[mode] = (c.fetch_demod().reshape(ncap, -1), c.fetch_bits().reshape(ncap, -1))
+        c.close()
+    assert np.array_equal(res["win"][0].view(np.uint32), res["valu"][0].view(np.uint32))
+    assert np.array_equal(res["win"][1], res["valu"][1])
+    for i in range(ncap):
+        z = odsp.cu8_to_fc32(flat[i * st:i * st + n])
+        y = odsp.freq_xlating_fir(z, taps, fc, FS, 1) if fc else odsp.fir_ccf(z, taps, 1)
+        v = odsp.mag2(y)
+        assert np.array_equal(res["win"][0][i].view(np.uint32), (np.float32(8.0) * v).view(np.uint32))
+        b, _, _ = odsp.slice_bits(v, 8.0, 0.05, 0.15, 50)
+        assert np.array_equal(res["win"][1][i], b)
+    # streaming: byte history carried between calls
+    u = flat[:n]
+    z = odsp.cu8_to_fc32(u)
+    v = odsp.mag2(odsp.freq_xlating_fir(z, taps, fc, FS, 1) if fc else odsp.fir_ccf(z, taps, 1))
+    c = _chain("win", FS, decim=1, center_freq=fc, taps=taps, demod=chain.DEMOD_MAG2, demod_gain=8.0, thr=(0.05, 0.15),
+               keep_n=50, tap_demod=True, max_samples=n, input_format="cu8")
+    cuts = sorted(set([0, 1, 2, 9, min(n, 2560), min(n, 2561), n // 2, n]))
+    fl = []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        c.process_iq(u[a:b])
+        fl.append(c.fetch_demod())
+    c.close()
+    assert np.array_equal(np.concatenate(fl).view(np.uint32), (np.float32(8.0) * v).view(np.uint32))

@@ -10,13 +10,16 @@ n = 1 << lg
 dev = torch.device("cuda", 0)
 g = torch.Generator(device=dev); g.manual_seed(1)
 iq = 0.3 * torch.randn((ncap, n, 2), generator=g, device=dev, dtype=torch.float32)
+cu8 = bool(os.environ.get("WIN_CU8"))
+if cu8:
+    iq = torch.clamp(torch.round(iq * 128.0 + 127.4), 0, 255).to(torch.uint8)
 rng = np.random.default_rng(nt)
 taps = (rng.standard_normal(nt) / nt ** 0.5).astype(np.float32)
 for mode in sys.argv[6:] or ["win", "mfma", "valu"]:
     os.environ["SDR_FRONTEND"] = mode
     c = chain.Chain(2e6, decim=1, taps=taps, demod=chain.DEMOD_QUAD if demod == "quad" else chain.DEMOD_MAG2,
                     thr=(-0.2, 0.2) if demod == "quad" else (0.05, 0.15), keep_n=keep, max_batch=ncap, max_frames=4, max_samples=n,
-                    center_freq=float(os.environ.get("WIN_FC", "0")))
+                    center_freq=float(os.environ.get("WIN_FC", "0")), input_format="cu8" if cu8 else "fc32")
     c.set_stream(torch.cuda.current_stream().cuda_stream)
     for _ in range(3):
         c.batch_process(iq)
