@@ -13,6 +13,7 @@ struct sdr_fm {
     std::string err;
     float *d_ataps = nullptr, *d_rtaps = nullptr;  // audio FIR (reversed), resampler taps
     int n_ataps = 0, n_rtaps = 0, L = 1, M = 1;
+    int audio_nw = 4;                         // waves per audio-FIR tile (SDR_FM_AUDIO_NW: tuning)
     bool audio_valu = false;                  // SDR_FM_AUDIO=valu: tuning/test override, read once at create
     double b0 = 0, p1 = 0;
     float *d_a2 = nullptr, *d_a3 = nullptr, *d_audio = nullptr;
@@ -136,6 +137,7 @@ extern "C" int sdr_fm_create(const sdr_fm_cfg* cfg, sdr_fm** out)
         if (nt < 1) return fm_fail(h, SDR_E_ARG, "audio filter design failed");
         h->n_ataps = nt;
         if (const char* e = getenv("SDR_FM_AUDIO")) h->audio_valu = !strcmp(e, "valu");
+        if (const char* e = getenv("SDR_FM_AUDIO_NW")) h->audio_nw = (atoi(e) == 1 || atoi(e) == 2) ? atoi(e) : 4;
         std::vector<float> rt(nt);
         for (int k = 0; k < nt; ++k) rt[nt - 1 - k] = buf[k];
         FMCHK(h, dev_alloc((void**)&h->d_ataps, nt * sizeof(float)));
@@ -264,7 +266,7 @@ extern "C" int sdr_fm_process(sdr_fm* h, const void* iq, size_t n, int is_dev, s
         // matrix-core form when its tile fits LDS and the band is mostly taps (ntaps >= 4*D: at most ~4x padding)
         int nw = 0;
         if (!h->audio_valu && h->n_ataps >= 4 * D)
-            for (nw = 4; nw >= 1; nw >>= 1)
+            for (nw = h->audio_nw; nw >= 1; nw >>= 1)
                 if (fir_mfma_lds_bytes(D, h->n_ataps, nw) <= 60 * 1024) break;
         if (nw >= 1) {
             const int TB = 256 * nw;

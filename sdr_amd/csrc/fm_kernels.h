@@ -34,7 +34,7 @@ __global__ void __launch_bounds__(256) k_fir_fff_decim(const float* __restrict__
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const int i = b + k * T + threadIdx.x;
-                r[k] = (i < count) ? src[i] : 0.f;
+                r[k] = src[i < count ? i : count - 1];   // unconditional (clamped): loads stay back to back
             }
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
@@ -119,9 +119,10 @@ __global__ void __launch_bounds__(256) k_fir_fff_mfma(const float* __restrict__ 
                 float4 r[FIR_MFMA_INFLIGHT];
 #pragma unroll
                 for (int k = 0; k < FIR_MFMA_INFLIGHT; ++k) {
+                    // unconditional, index clamped: a load under `if` is an exec-masked block of its own and the
+                    // compiler waits for the previous load before it (one HBM round trip per load)
                     const int c = b + k * T + t;
-                    r[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (c < nch) r[k] = src4[c];
+                    r[k] = src4[c < nch ? c : nch - 1];
                 }
 #pragma unroll
                 for (int k = 0; k < FIR_MFMA_INFLIGHT; ++k) {

@@ -158,6 +158,60 @@ __device__ __forceinline__ void slice_tile_xn(const bool* valid, const float* v,
     }
 }
 
+// The K loop of one wavefront: 256 outputs (16 groups x 16) from the padded sample image `smp` and the tap
+// table at `ldsf` (tapL[15D + idx] = rtaps[idx]).  `odd` = the image starts one sample before the tile.
+__device__ __forceinline__ void mfma_kloop(const float* ldsf, const float* smp, const int D, const int ksteps,
+                                           const int odd, const int lane, const int wave, f32x4& accR, f32x4& accI)
+{
+    const int BK = 16 * D;
+    const int g = lane & 15, kq = lane >> 4;
+    const int G = wave * 16 + g;                       // group index inside the workgroup tile
+    const float* ta = ldsf + (15 * D + kq - D * g);    // A[i=g][k]: tap index 4kk + kq - g*D
+    const float* sb = smp + 2 * (odd + BK * G + kq) + 4 * G;
+    // K steps in groups of 4 (= 16 samples; a pad block is D groups): constant
+    // offsets inside a group, one pointer bump per group, the pad added per
+    // block.  A lane that starts at offset 4 (odd tile start, kq = 3) crosses
+    // into the next block one step early: `late` on the block's last step.
+    const int late = (odd + kq >= 4) ? 4 : 0;
+    const int ngrp = ksteps >> 2, tail = ksteps & 3;
+    int gi = 0;
+    float a[4], an[4];
+    float2 b[4], bn[4];
+    auto load = [&](float* av, float2* bv) {
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) av[s4] = ta[4 * s4];
+#pragma unroll
+        for (int s4 = 0; s4 < 3; ++s4) bv[s4] = *reinterpret_cast<const float2*>(sb + 8 * s4);
+        bv[3] = *reinterpret_cast<const float2*>(sb + 24 + ((gi == D - 1) ? late : 0));
+        ta += 16;
+        sb += 32;
+        if (++gi == D) {
+            gi = 0;
+            sb += 4;
+        }
+    };
+    load(a, b);
+    for (int grp = 0; grp < ngrp; ++grp) {
+        load(an, bn);  // operands of the next group are fetched while this group's 8 MFMAs run
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            accR = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s4], b[s4].x, accR, 0, 0, 0);
+            accI = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s4], b[s4].y, accI, 0, 0, 0);
+        }
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            a[s4] = an[s4];
+            b[s4] = bn[s4];
+        }
+    }
+#pragma unroll
+    for (int s4 = 0; s4 < 3; ++s4)
+        if (s4 < tail) {
+            accR = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s4], b[s4].x, accR, 0, 0, 0);
+            accI = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s4], b[s4].y, accI, 0, 0, 0);
+        }
+}
+
 #define MFMA_ROT_K 4   // 16-B loads in flight per lane in the rotating staging loop (8: 145 VGPRs, 3 waves per SIMD)
 // blockDim.x = 64*nw, P.tile_out = 256*nw - q.  Dynamic LDS: tap table | padded samples (aliased by the output tile).
 __global__ void __launch_bounds__(256) k_frontend_mfma(FrontParams P)
@@ -246,11 +300,11 @@ __global__ void __launch_bounds__(256) k_frontend_mfma(FrontParams P)
 #pragma unroll
             for (int k = 0; k < MFMA_ROT_K; ++k) {
                 const int sc = c0 + k * T + t;
-                rg[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (sc < nsrc) {
-                    if (interior)
-                        rg[k] = x4[sc];
-                    else {
+                if (interior)
+                    rg[k] = x4[sc < nsrc ? sc : nsrc - 1];   // unconditional (clamped): the loads stay back to back
+                else {
+                    rg[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (sc < nsrc) {
                         const float2 a = fetch(lo_al + 2LL * sc), b = fetch(lo_al + 2LL * sc + 1);
                         rg[k] = make_float4(a.x, a.y, b.x, b.y);
                     }
@@ -310,53 +364,24 @@ __global__ void __launch_bounds__(256) k_frontend_mfma(FrontParams P)
 
     // ---- banded Toeplitz product on the f32 matrix cores
     f32x4 accR = {0.f, 0.f, 0.f, 0.f}, accI = {0.f, 0.f, 0.f, 0.f};
-    {
-        const int g = lane & 15, kq = lane >> 4;
-        const int G = wave * 16 + g;                       // group index inside the workgroup tile
-        const float* ta = ldsf + (15 * D + kq - D * g);    // A[i=g][k]: tap index 4kk + kq - g*D
-        const float* sb = smp + 2 * (odd + BK * G + kq) + 4 * G;
-        // K steps in groups of 4 (= 16 samples; a pad block is D groups): constant
-        // offsets inside a group, one pointer bump per group, the pad added per
-        // block.  A lane that starts at offset 4 (odd tile start, kq = 3) crosses
-        // into the next block one step early: `late` on the block's last step.
-        const int late = (odd + kq >= 4) ? 4 : 0;
-        const int ngrp = ksteps >> 2, tail = ksteps & 3;
-        int gi = 0;
-        float a[4], an[4];
-        float2 b[4], bn[4];
-        auto load = [&](float* av, float2* bv) {
+    mfma_kloop(ldsf, smp, D, ksteps, odd, lane, wave, accR, accI);
+    if (P.demod == SDR_DEMOD_NONE && !P.nco_tab) {
+        // complex output with nothing behind the filter (FM chain's resampler stage, squelch input): straight from
+        // the accumulators, D[row = 4*(lane>>4) + r][col = lane&15] = four consecutive outputs per lane (32 B) --
+        // no pass through LDS, no barriers
+        if (P.tap) {
+            const long long m = m_t0 + wave * 256 + 16 * (lane & 15) + 4 * (lane >> 4);
+            float2* const o = reinterpret_cast<float2*>(P.tap + (long long)cap * P.tap_stride) + m;
+            if (m + 4 <= P.nout && (reinterpret_cast<uintptr_t>(o) & 15) == 0) {
+                reinterpret_cast<float4*>(o)[0] = make_float4(accR[0], accI[0], accR[1], accI[1]);
+                reinterpret_cast<float4*>(o)[1] = make_float4(accR[2], accI[2], accR[3], accI[3]);
+            } else {
 #pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) av[s4] = ta[4 * s4];
-#pragma unroll
-            for (int s4 = 0; s4 < 3; ++s4) bv[s4] = *reinterpret_cast<const float2*>(sb + 8 * s4);
-            bv[3] = *reinterpret_cast<const float2*>(sb + 24 + ((gi == D - 1) ? late : 0));
-            ta += 16;
-            sb += 32;
-            if (++gi == D) {
-                gi = 0;
-                sb += 4;
-            }
-        };
-        load(a, b);
-        for (int grp = 0; grp < ngrp; ++grp) {
-            load(an, bn);  // operands of the next group are fetched while this group's 8 MFMAs run
-#pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) {
-                accR = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s4], b[s4].x, accR, 0, 0, 0);
-                accI = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s4], b[s4].y, accI, 0, 0, 0);
-            }
-#pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) {
-                a[s4] = an[s4];
-                b[s4] = bn[s4];
+                for (int r = 0; r < 4; ++r)
+                    if (m + r < P.nout) o[r] = make_float2(accR[r], accI[r]);
             }
         }
-#pragma unroll
-        for (int s4 = 0; s4 < 3; ++s4)
-            if (s4 < tail) {
-                accR = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s4], b[s4].x, accR, 0, 0, 0);
-                accI = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s4], b[s4].y, accI, 0, 0, 0);
-            }
+        return;
     }
     __syncthreads();  // every wave is done with the samples: the output tile aliases them
     float2* const ybuf = reinterpret_cast<float2*>(smp);
@@ -427,4 +452,186 @@ __global__ void __launch_bounds__(256) k_frontend_mfma(FrontParams P)
     if (!P.do_slice) return;
     slice_tile_xn<4>(valid, v, 4 * t, m_t0, P.lo, P.hi, P.keep_n, P.keep_c0, P.bits + (long long)cap * P.bits_stride,
                   P.tsum + (long long)cap * P.tiles_per_capture + tile, sh);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// The same product for a stage WITHOUT demodulation (complex output: the FM chain's freq_xlating ->
+// rational_resampler_ccc stage, a prefilter stage) with TWO TEAMS of four wavefronts per workgroup.
+// k_frontend_mfma's waves all walk the same phases -- stage (wait on HBM, rotate), K loop, epilogue -- and the
+// workgroups of a CU start together and take equally long, so they stay in step: the four waves of a SIMD
+// queue for the matrix pipe during the K loop and leave it idle during the rest (SQ_VALU_MFMA_BUSY 44 % of the
+// CU-busy cycles at 131 taps / 4; a wave spends 12 % of its life in MFMAs, 13 % in vector instructions and
+// the rest waiting).  Here the two teams of a workgroup run in ANTIPHASE, held there by one barrier per phase:
+//
+//   phase      0        1        2        3
+//   team 0   commit   K loop   commit   K loop     commit = rotate the tile's samples (registers -> LDS) and
+//   team 1     -      commit   K loop   commit              issue the loads of the team's next tile
+//
+// Wave w of team 0 and wave w of team 1 share a SIMD (8 waves over 4 SIMDs), so each SIMD always has one
+// wave feeding the matrix pipe while the other does the vector and memory work.  Each team owns one sample
+// buffer (its K loop and its next commit are a barrier apart) and keeps its next tile's 16-B chunks in
+// registers while it runs the K loop, so the HBM latency is hidden too.  Outputs go straight from the
+// accumulators to memory.  Same products in the same order as k_frontend_mfma: bit-identical.
+// P.tile_out = 1024; blockDim.x = 512; grid.x = ceil(tiles / tpw); dynamic LDS mfma2_lds_bytes().
+// workgroup barrier that orders LDS accesses only: lgkmcnt(0), vmcnt and expcnt left alone (gfx9 s_waitcnt encoding)
+__device__ __forceinline__ void lds_only_barrier()
+{
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_s_barrier();
+}
+
+#define MFMA2_NCH 9   // 16-B chunks per lane per tile (host: the tile's chunks must fit, D <= 4 for ~130 taps)
+__host__ __device__ inline int mfma2_npos(int D, int ntaps) { return 1023 * D + ntaps + 40; }
+__host__ __device__ inline int mfma2_buf_floats(int D, int ntaps)
+{
+    const int npos = mfma2_npos(D, ntaps) + 2;
+    return (2 * npos + 4 * (npos / (16 * D) + 2) + 3) & ~3;
+}
+__host__ __device__ inline int mfma2_tap_floats(int D, int ntaps)
+{
+    const int ksteps = (15 * D + ntaps + 3) >> 2;
+    return (15 * D + 4 * (ksteps + 8) + 3) & ~3;
+}
+__host__ __device__ inline size_t mfma2_lds_bytes(int D, int ntaps)
+{
+    return ((size_t)mfma2_tap_floats(D, ntaps) + 2 * (size_t)mfma2_buf_floats(D, ntaps)) * sizeof(float) +
+           SDR_NCO_TAB * sizeof(float2);   // + the NCO table
+}
+
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) k_frontend_mfma2(FrontParams P, int tpw)
+{
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    float* const ldsf = reinterpret_cast<float*>(smem_raw);
+    constexpr int T = 256, TB = 1024, NCH = MFMA2_NCH;
+    const int team = threadIdx.x >> 8, t = threadIdx.x & 255, lane = t & 63, wave = t >> 6;
+    const int cap = blockIdx.y;
+    const int D = P.D, ntaps = P.ntaps;
+    const int ksteps = (15 * D + ntaps + 3) >> 2;
+    const int ntl = mfma2_tap_floats(D, ntaps);
+    const int npos = mfma2_npos(D, ntaps);
+    const int per8 = 8 * D;                                // source chunks per pad block
+    float* const smp = ldsf + ntl + team * mfma2_buf_floats(D, ntaps);
+    const float2* __restrict__ x = P.x + (long long)cap * P.stride;
+    const int tile0 = blockIdx.x * tpw;
+    const int ntile = (P.tiles_per_capture - tile0 < tpw) ? P.tiles_per_capture - tile0 : tpw;
+    const int n_my = (ntile - team + 1) >> 1;              // this team's tiles: tile0 + team + 2j
+
+    for (int i = threadIdx.x; i < ntl; i += 2 * T) {
+        const int idx = i - 15 * D;
+        ldsf[i] = (idx >= 0 && idx < ntaps) ? P.rtaps[idx] : 0.f;
+    }
+    // the 1024-entry NCO table in LDS: one lookup per input sample, scattered over the 8 KB table -- through the
+    // L1 every lane of such a gather is a cache line of its own, 64 cycles of the CU's one texture path per wave
+    // instruction: 0.13 ms per 2^26 samples, more than the whole K loop
+    float2* const s_nco = reinterpret_cast<float2*>(ldsf + ntl + 2 * mfma2_buf_floats(D, ntaps));
+    if (P.pre_tab)
+        for (int i = threadIdx.x; i < SDR_NCO_TAB; i += 2 * T) s_nco[i] = P.pre_tab[i];
+    auto fetch = [&](long long idx) -> float2 {
+        if (idx >= 0) return idx < P.n ? x[idx] : make_float2(0.f, 0.f);
+        if (P.hist && idx >= -(long long)P.hist_len) return P.hist[P.hist_len + idx];
+        return make_float2(0.f, 0.f);
+    };
+    // TB*D is even: every tile of the capture starts with the same parity
+    const int odd = P.vec_ok ? (int)(((long long)cap * P.stride + P.in0 - (ntaps - 1)) & 1) : 0;
+    const int nsrc = (npos + odd + 1) >> 1;                // 16-B source chunks (two samples) per tile
+    float4 rg[NCH];                                        // lane t holds chunks t, t + T, ... of the team's next tile
+    auto tile_lo = [&](int tile) -> long long { return P.in0 + (long long)tile * TB * D - (ntaps - 1) - odd; };
+    auto is_interior = [&](long long lo_al) -> bool { return P.vec_ok && lo_al >= 0 && lo_al + 2LL * nsrc <= P.n; };   // uniform
+    auto issue = [&](int tile) {
+        const long long lo_al = tile_lo(tile);
+        if (!is_interior(lo_al)) return;                   // edge tiles are fetched, guarded, when they are committed
+        const float4* __restrict__ x4 = reinterpret_cast<const float4*>(x + lo_al);
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            // unconditional (index clamped): a load under `if (c < nsrc)` becomes an exec-masked block of its
+            // own and the compiler waits for the previous load before each -- nine HBM round trips per tile
+            const int c = k * T + t;
+            rg[k] = x4[c < nsrc ? c : nsrc - 1];
+        }
+    };
+    auto rotate2 = [&](float4 u, unsigned long long ph) -> float4 {   // two samples, phases ph and ph + inc
+        const float2 r0 = nco_eval(s_nco, ph), r1 = nco_eval(s_nco, ph + P.pre_inc);
+        float4 v;
+        v.x = __builtin_fmaf(u.x, r0.x, -(u.y * r0.y));
+        v.y = __builtin_fmaf(u.x, r0.y, u.y * r0.x);
+        v.z = __builtin_fmaf(u.z, r1.x, -(u.w * r1.y));
+        v.w = __builtin_fmaf(u.z, r1.y, u.w * r1.x);
+        return v;
+    };
+    auto commit = [&](int tile) {
+        const long long lo_al = tile_lo(tile);
+        unsigned long long ph = 0ull, dph = 0ull;
+        if (P.pre_tab) {   // freq_xlating_fir_filter with taps = [1] ahead of the resampler: rotate on the way in
+            ph = (P.pre_idx0 + (unsigned long long)(lo_al + 2LL * t)) * P.pre_inc;
+            dph = P.pre_inc * (unsigned long long)(2 * T);
+        }
+        int quo = t / per8, rem = t - quo * per8;
+        const int dq = T / per8, dr = T - dq * per8;
+        if (!is_interior(lo_al)) {
+            // first / last tiles of a capture (history, zero padding) and unaligned buffers: chunk by chunk, rolled
+#pragma unroll 1
+            for (int c = t; c < nsrc; c += T) {
+                const float2 a = fetch(lo_al + 2LL * c), b = fetch(lo_al + 2LL * c + 1);
+                float4 v = make_float4(a.x, a.y, b.x, b.y);
+                if (P.pre_tab) v = rotate2(v, ph);
+                *reinterpret_cast<float4*>(smp + 4 * (c + quo)) = v;
+                ph += dph;
+                quo += dq;
+                rem += dr;
+                if (rem >= per8) {
+                    rem -= per8;
+                    ++quo;
+                }
+            }
+            return;
+        }
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            const int c = k * T + t;
+            if (c < nsrc) {
+                float4 v = rg[k];
+                if (P.pre_tab) v = rotate2(v, ph);
+                *reinterpret_cast<float4*>(smp + 4 * (c + quo)) = v;
+            }
+            ph += dph;
+            quo += dq;
+            rem += dr;
+            if (rem >= per8) {
+                rem -= per8;
+                ++quo;
+            }
+        }
+    };
+
+    float2* const dst = reinterpret_cast<float2*>(P.tap + (long long)cap * P.tap_stride);
+    if (n_my > 0) issue(tile0 + team);
+    const int nphase = ntile + 1;                          // team 0: phases 0 .. 2*n0-1, team 1: 1 .. 2*n1
+    for (int p = 0; p < nphase; ++p) {
+        const int s = p - team;                            // this team's step: even = commit, odd = K loop
+        if (s >= 0 && (s >> 1) < n_my) {
+            const int j = s >> 1, tile = tile0 + team + 2 * j;
+            if (!(s & 1)) {
+                commit(tile);
+                if (j + 1 < n_my) issue(tile + 2);
+            } else {
+                f32x4 accR = {0.f, 0.f, 0.f, 0.f}, accI = {0.f, 0.f, 0.f, 0.f};
+                mfma_kloop(ldsf, smp, D, ksteps, odd, lane, wave, accR, accI);
+                // D[row = 4*(lane>>4) + r][col = lane&15]: outputs 16*col + row of this wave's 256 -- four in a row per lane
+                const long long m = (long long)tile * TB + wave * 256 + 16 * (lane & 15) + 4 * (lane >> 4);
+                float2* const o = dst + m;
+                if (m + 4 <= P.nout && (reinterpret_cast<uintptr_t>(o) & 15) == 0) {
+                    reinterpret_cast<float4*>(o)[0] = make_float4(accR[0], accI[0], accR[1], accI[1]);
+                    reinterpret_cast<float4*>(o)[1] = make_float4(accR[2], accI[2], accR[3], accI[3]);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (m + r < P.nout) o[r] = make_float2(accR[r], accI[r]);
+                }
+            }
+        }
+        // The team that committed may now run its K loop, the one that ran it may overwrite its buffer.  NOT
+        // __syncthreads(): its fence also waits for the global loads just issued and the outputs just stored
+        // (vmcnt(0)), which put one HBM round trip into every phase.  Only LDS traffic has to be complete.
+        lds_only_barrier();
+    }
 }

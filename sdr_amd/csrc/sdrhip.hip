@@ -111,6 +111,7 @@ struct sdr_handle {
     // ablation switches (env SDR_NO_KTAPS / SDR_NO_RAW8 / SDR_NO_REUSE / SDR_NO_SEG / SDR_NO_PIECES, SDR_TILE):
     // read ONCE in sdr_create, never on the call path
     bool no_ktaps = false, no_raw8 = false, no_reuse = false, no_seg = false, no_pieces = false;
+    bool mfma2_ok = false;    // k_frontend_mfma2 may be launched (its > 64 KiB of dynamic LDS was granted; SDR_NO_MFMA2 unset)
     int tile_override = 0;
     long long seg_min_row = SDR_SEG_MIN_ROW;   // rows this long take the segment- and piece-parallel back end (env SDR_SEG_MIN)
 
@@ -521,6 +522,9 @@ extern "C" int sdr_create(const sdr_chain_cfg* cfg, sdr_handle** out)
     h->no_reuse = getenv("SDR_NO_REUSE") != nullptr;
     h->no_seg = getenv("SDR_NO_SEG") != nullptr;
     h->no_pieces = getenv("SDR_NO_PIECES") != nullptr;
+    if (!getenv("SDR_NO_MFMA2"))   // two sample buffers of a 1024-output tile: up to 88 KiB of dynamic LDS, above the 64 KiB default
+        h->mfma2_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(k_frontend_mfma2), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          88 * 1024) == hipSuccess;
     if (const char* te = getenv("SDR_TILE")) h->tile_override = atoi(te);
     if (const char* te = getenv("SDR_SEG_MIN")) h->seg_min_row = atoll(te) >= 16384 ? atoll(te) : 16384;
     (void)hipDeviceGetAttribute(&h->num_cus, hipDeviceAttributeMultiprocessorCount, h->device);
@@ -780,6 +784,8 @@ struct CallGeom {
     bool use_lds;
     bool mfma;   // k_frontend_mfma: T = 64*nw threads, 256*nw FIR outputs per tile
     bool win = false;  // k_frontend_win: T threads, T*WIN_R FIR outputs per tile
+    int mfma2 = 0;     // >0: k_frontend_mfma2 (two teams, no demodulation), this many tiles per workgroup
+    size_t mfma2_lds = 0;
     int pipe_nch = 0;  // >0: k_frontend_pipe with this many 16-B chunks per lane per tile
     int pipe_tpw = 0;  // tiles per workgroup
 };
@@ -847,7 +853,10 @@ static int launch_front(sdr_handle* h, const float2* x, long long stride, long l
         hipLaunchKernelGGL(k_frontend_win<true>, grid, block, g.lds, h->stream, P);
     else if (g.win)
         hipLaunchKernelGGL(k_frontend_win<false>, grid, block, g.lds, h->stream, P);
-    else if (g.mfma)
+    else if (g.mfma && g.mfma2) {
+        dim3 dgrid((g.tiles + g.mfma2 - 1) / g.mfma2, ncap);
+        hipLaunchKernelGGL(k_frontend_mfma2, dgrid, dim3(512), g.mfma2_lds, h->stream, P, g.mfma2);
+    } else if (g.mfma)
         hipLaunchKernelGGL(k_frontend_mfma, grid, block, g.lds, h->stream, P);
     else if (h->in_fmt == SDR_IN_CU8 && P.vec_ok && !P.pre_tab && P.ktaps_n > 0 && g.use_lds && !h->no_raw8) {
         // bytes stay bytes in LDS: (count + up to 7 samples of alignment) rounded up to 16-B chunks
@@ -1074,6 +1083,7 @@ static void fill_geom(const sdr_handle* h, long long nout, long long in0, long l
     const long long kn = h->cfg.keep_n;
     g.ne = nout > keep_c0 ? (nout - keep_c0 + kn - 1) / kn : 0;
     const int q = (h->cfg.demod == SDR_DEMOD_QUAD && !to_squelch) ? 1 : 0;
+    g.mfma2 = 0;
     g.win = pick_win(h, nout, g.T, g.lds);
     g.mfma = !g.win && pick_mfma(h, g.T, g.lds);
     if (g.win) {
@@ -1082,6 +1092,18 @@ static void fill_geom(const sdr_handle* h, long long nout, long long in0, long l
     } else if (g.mfma) {
         g.use_lds = true;
         g.tile_out = 4 * g.T - q;
+        // complex output, no NCO behind the filter, full-size tiles: the two-team form when a tile's chunks fit
+        // the registers of one team and two sample buffers fit the LDS
+        const int D = h->cfg.decim, nt = h->ntaps;
+        const bool plain = (h->cfg.demod == SDR_DEMOD_NONE || to_squelch) && (h->cfg.center_freq == 0.0 || h->prerotate);
+        const long long tiles = (nout + 1023) / 1024;
+        if (plain && g.T == 256 && h->mfma2_ok && tiles >= 2 && (mfma2_npos(D, nt) + 2) / 2 <= MFMA2_NCH * 256 &&
+            mfma2_lds_bytes(D, nt) <= 88 * 1024) {
+            g.mfma2_lds = mfma2_lds_bytes(D, nt);
+            long long tpw = tiles / 512;                   // two workgroups per CU's worth before tiles are chained further
+            if (const char* e = getenv("SDR_MFMA2_TPW")) tpw = atoi(e);   // tuning
+            g.mfma2 = (int)(tpw < 2 ? 2 : (tpw > 64 ? 64 : tpw));
+        }
     } else {
         pick_tile(h, g.T, g.lds, g.use_lds);
         g.tile_out = g.T - q;

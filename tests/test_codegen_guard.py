@@ -71,7 +71,7 @@ def test_hot_kernels_use_no_scratch_memory(device_asm):
     private (scratch) memory -- every k_backend launch 2.4x slower, identical results.  The kernels on the
     measured paths must keep their state in registers: private_segment_fixed_size == 0."""
     hot = ["_Z9k_backend10BackParams", "_Z14k_frontend_winILb0EEv11FrontParams", "_Z14k_frontend_winILb1EEv11FrontParams",
-           "_Z15k_frontend_mfma11FrontParams", "_Z14k_fir_fff_mfmaPKfS0_ixxxS0_iiPf",
+           "_Z15k_frontend_mfma11FrontParams", "_Z14k_fir_fff_mfmaPKfS0_ixxxS0_iiPf", "_Z16k_frontend_mfma211FrontParamsi",
            "_Z10k_frontendILb1ELb0EEv11FrontParams10FrontKTaps", "_Z15k_frontend_raw811FrontParams10FrontKTaps",
            "_Z5k_pfbILi8EEv9PfbParams", "_Z10k_runs_seg10BackParams", "_Z15k_decode_pieces10BackParams"]
     for sym in hot:

@@ -123,3 +123,44 @@ def test_auto_mode_equals_both_kernels_on_the_r_shape():
     np.testing.assert_array_equal(bits["auto"], bits["valu"])
     np.testing.assert_array_equal(bits["mfma"], bits["valu"])
     assert bits["valu"].any() and not bits["valu"].all()
+
+
+@pytest.mark.parametrize("D,ntaps", [(1, 27), (2, 61), (4, 131), (3, 200)])
+def test_mfma_two_team_kernel_batch_stream_and_fallback(D, ntaps, monkeypatch):
+    """k_frontend_mfma2 (two teams per workgroup in antiphase, tiles chained, complex output) against the oracle
+    and against k_frontend_mfma (SDR_NO_MFMA2, read at create): aligned and unaligned capture strides, a batch,
+    ragged streaming chunks through the FIR history, tile counts that leave one team a tile short."""
+    import ctypes as C
+    from sdr_amd import _lib, chain
+    rng = np.random.default_rng(D * 1000 + ntaps)
+    taps = rng.standard_normal(ntaps).astype(np.float32) / np.float32(ntaps ** 0.5)
+    for tiles_x, extra in ((5, 0), (2, 1), (9, 0)):
+        n = tiles_x * 1024 * D + 333
+        ncap = 2
+        st = n + (n & 1) + extra                      # even stride: 16-B loads; odd: guarded, sample by sample
+        flat = _iq(ncap * st, n + extra)
+        got = {}
+        for two in (True, False):
+            if two:
+                monkeypatch.delenv("SDR_NO_MFMA2", raising=False)
+            else:
+                monkeypatch.setenv("SDR_NO_MFMA2", "1")
+            c = _chain("mfma", 1e6, decim=D, taps=taps, demod=chain.DEMOD_NONE, tap_demod=True, max_batch=ncap, max_samples=n)
+            _lib.check(c._h, c._L.sdr_batch_process(c._h, C.c_void_p(flat.ctypes.data), n, st, ncap, 0, C.byref(c.out)))
+            got[two] = c.fetch_demod().reshape(ncap, -1)
+            c.close()
+        assert _same_words(got[True], got[False])
+        for i in range(ncap):
+            assert _same_words(got[True][i], odsp.fir_ccf(flat[i * st:i * st + n], taps, D))
+    monkeypatch.delenv("SDR_NO_MFMA2", raising=False)
+    n = 7 * 1024 * D + 5
+    x = _iq(n, 3 * D + ntaps)
+    want = odsp.fir_ccf(x, taps, D)
+    c = _chain("mfma", 1e6, decim=D, taps=taps, demod=chain.DEMOD_NONE, tap_demod=True, max_samples=n)
+    cuts = [0, 1, 2 * 1024 * D + 1, 2 * 1024 * D + 2, 5 * 1024 * D + 7, n]
+    parts = []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        c.process_iq(x[a:b])
+        parts.append(c.fetch_demod())
+    c.close()
+    assert _same_words(np.concatenate(parts), want)
