@@ -111,6 +111,7 @@ struct sdr_handle {
     // ablation switches (env SDR_NO_KTAPS / SDR_NO_RAW8 / SDR_NO_REUSE / SDR_NO_SEG / SDR_NO_PIECES, SDR_TILE):
     // read ONCE in sdr_create, never on the call path
     bool no_ktaps = false, no_raw8 = false, no_reuse = false, no_seg = false, no_pieces = false;
+    int mfma2_tpw = 0;
     bool mfma2_ok = false;    // k_frontend_mfma2 may be launched (its > 64 KiB of dynamic LDS was granted; SDR_NO_MFMA2 unset)
     int tile_override = 0;
     long long seg_min_row = SDR_SEG_MIN_ROW;   // rows this long take the segment- and piece-parallel back end (env SDR_SEG_MIN)
@@ -522,6 +523,7 @@ extern "C" int sdr_create(const sdr_chain_cfg* cfg, sdr_handle** out)
     h->no_reuse = getenv("SDR_NO_REUSE") != nullptr;
     h->no_seg = getenv("SDR_NO_SEG") != nullptr;
     h->no_pieces = getenv("SDR_NO_PIECES") != nullptr;
+    if (const char* e = getenv("SDR_MFMA2_TPW")) h->mfma2_tpw = atoi(e);
     if (!getenv("SDR_NO_MFMA2"))   // two sample buffers of a 1024-output tile: up to 88 KiB of dynamic LDS, above the 64 KiB default
         h->mfma2_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(k_frontend_mfma2), hipFuncAttributeMaxDynamicSharedMemorySize,
                                           88 * 1024) == hipSuccess;
@@ -1101,7 +1103,7 @@ static void fill_geom(const sdr_handle* h, long long nout, long long in0, long l
             mfma2_lds_bytes(D, nt) <= 88 * 1024) {
             g.mfma2_lds = mfma2_lds_bytes(D, nt);
             long long tpw = tiles / 512;                   // two workgroups per CU's worth before tiles are chained further
-            if (const char* e = getenv("SDR_MFMA2_TPW")) tpw = atoi(e);   // tuning
+            if (h->mfma2_tpw > 0) tpw = h->mfma2_tpw;      // SDR_MFMA2_TPW (tuning), read at create
             g.mfma2 = (int)(tpw < 2 ? 2 : (tpw > 64 ? 64 : tpw));
         }
     } else {
