@@ -28,12 +28,15 @@ __device__ __forceinline__ long long rl_blocks(const int8_t* __restrict__ bits, 
             const long long j0 = blk + tid * RL_BYTES;
 #pragma unroll
             for (int q = 0; q < RL_W / 4; ++q) {
-                uint4 a = make_uint4(0u, 0u, 0u, 0u);
-                if (j0 + 16 * q < nb) a = *reinterpret_cast<const uint4*>(bits + j0 + 16 * q);
+                // unconditional (pieces past the row's end re-read its first piece; their words are masked by
+                // `valid` below): a load under `if` is an exec-masked block of its own that the compiler puts a
+                // wait for the previous load in front of -- four round trips per block instead of one
+                const long long off = (j0 + 16 * q < nb) ? j0 + 16 * q : 0;
+                const uint4 a = *reinterpret_cast<const uint4*>(bits + off);
                 o[4 * q] = a.x; o[4 * q + 1] = a.y; o[4 * q + 2] = a.z; o[4 * q + 3] = a.w;
             }
-            pbyte = 0;
-            if (j0 < nb) pbyte = j0 > 0 ? (unsigned)(unsigned char)bits[j0 - 1] : (o[0] & 0xffu);
+            const unsigned pb = (unsigned)(unsigned char)bits[(j0 > 0 && j0 < nb) ? j0 - 1 : 0];
+            pbyte = (j0 < nb) ? (j0 > 0 ? pb : (o[0] & 0xffu)) : 0u;
         };
         unsigned wd[RL_W], prevb;
         int par = 0;
@@ -65,7 +68,8 @@ __device__ __forceinline__ long long rl_blocks(const int8_t* __restrict__ bits, 
             int* const wt = s_wtot + (par << 2);
             par ^= 1;
             if (lane == 63) wt[wv] = incl;
-            __syncthreads();   // the only barrier of a round: the next round writes the other set of totals
+            lds_only_barrier();   // the only barrier of a round (the next round writes the other set of totals); it must
+                                  // not wait for the next block's loads, which are in flight on purpose
             int wbase = 0, total = 0;
             for (int w = 0; w < 4; ++w) {
                 if (w < wv) wbase += wt[w];
@@ -296,7 +300,7 @@ __global__ void __launch_bounds__(BK_THREADS, 6) k_backend(BackParams P)
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         const int i = i0 + 64 * u + lane;
-                        at[u] = i < n_s ? from[i] : 0;
+                        at[u] = from[i < n_s ? i : 0];   // unconditional: the four loads stay back to back
                     }
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {

@@ -473,13 +473,6 @@ __global__ void __launch_bounds__(256) k_frontend_mfma(FrontParams P)
 // registers while it runs the K loop, so the HBM latency is hidden too.  Outputs go straight from the
 // accumulators to memory.  Same products in the same order as k_frontend_mfma: bit-identical.
 // P.tile_out = 1024; blockDim.x = 512; grid.x = ceil(tiles / tpw); dynamic LDS mfma2_lds_bytes().
-// workgroup barrier that orders LDS accesses only: lgkmcnt(0), vmcnt and expcnt left alone (gfx9 s_waitcnt encoding)
-__device__ __forceinline__ void lds_only_barrier()
-{
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    __builtin_amdgcn_s_barrier();
-}
-
 #define MFMA2_NCH 9   // 16-B chunks per lane per tile (host: the tile's chunks must fit, D <= 4 for ~130 taps)
 __host__ __device__ inline int mfma2_npos(int D, int ntaps) { return 1023 * D + ntaps + 40; }
 __host__ __device__ inline int mfma2_buf_floats(int D, int ntaps)

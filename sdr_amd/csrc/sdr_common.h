@@ -42,6 +42,17 @@ struct RuleState {
     unsigned char bits[512];
 };
 
+#if defined(__HIPCC__)
+// Workgroup barrier that orders LDS accesses only: s_waitcnt lgkmcnt(0) (vmcnt and expcnt left alone; gfx9 encoding)
+// + s_barrier.  __syncthreads() also fences global memory (vmcnt(0)): a barrier inside a loop that keeps loads of
+// the next round in flight, or right behind output stores, then waits for an HBM round trip it does not need.
+__device__ __forceinline__ void lds_only_barrier()
+{
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_s_barrier();
+}
+#endif
+
 struct FrontParams {
     const float2* x;        // capture 0, sample 0
     const float2* hist;     // streaming: hist_len samples that precede x[0]; nullptr = zeros
