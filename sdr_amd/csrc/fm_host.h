@@ -312,9 +312,15 @@ extern "C" int sdr_fm_process(sdr_fm* h, const void* iq, size_t n, int is_dev, s
     if (h->n4 > 0) {
         int blocks = (int)((h->n4 + 255) / 256);
         const int hv = h->e_in < (unsigned long long)h->ehist_len ? (int)h->e_in : h->ehist_len;
-        hipLaunchKernelGGL(k_resample_fff, dim3(blocks), dim3(256), 0, h->stream, h->d_a3,
-                           h->d_ehist[h->esel] + (h->ehist_len - hv), hv, h->n2, (long long)h->e_in, (long long)h->e_out,
-                           h->n4, h->d_rtaps, h->n_rtaps, h->L, h->M, h->cfg.volume, h->d_audio);
+        const size_t rlds = resample_lds_bytes(h->n_rtaps, h->L, h->M);
+        if (rlds <= 48 * 1024)
+            hipLaunchKernelGGL(k_resample_fff_lds, dim3(blocks), dim3(256), rlds, h->stream, h->d_a3,
+                               h->d_ehist[h->esel] + (h->ehist_len - hv), hv, h->n2, (long long)h->e_in, (long long)h->e_out,
+                               h->n4, h->d_rtaps, h->n_rtaps, h->L, h->M, h->cfg.volume, h->d_audio);
+        else   // a polyphase table that does not fit LDS: every step from global memory
+            hipLaunchKernelGGL(k_resample_fff, dim3(blocks), dim3(256), 0, h->stream, h->d_a3,
+                               h->d_ehist[h->esel] + (h->ehist_len - hv), hv, h->n2, (long long)h->e_in, (long long)h->e_out,
+                               h->n4, h->d_rtaps, h->n_rtaps, h->L, h->M, h->cfg.volume, h->d_audio);
         FMCHK(h, hipGetLastError());
     }
     rc = fm_hist_update(h, h->d_ehist, h->esel, h->ehist_len, h->d_a3, h->n2);

@@ -190,26 +190,38 @@ __device__ __forceinline__ void mfma_kloop(const float* ldsf, const float* smp, 
             sb += 4;
         }
     };
+    auto mfma8 = [&](const float* av, const float2* bv) {
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            accR = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s4], bv[s4].x, accR, 0, 0, 0);
+            accI = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s4], bv[s4].y, accI, 0, 0, 0);
+        }
+    };
+    auto mfma_tail = [&](const float* av, const float2* bv) {
+#pragma unroll
+        for (int s4 = 0; s4 < 3; ++s4)
+            if (s4 < tail) {
+                accR = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s4], bv[s4].x, accR, 0, 0, 0);
+                accI = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s4], bv[s4].y, accI, 0, 0, 0);
+            }
+    };
+    // Two operand sets used alternately (the loop is unrolled by two groups): the operands of the next group are
+    // fetched while this group's 8 MFMAs run, and no register is copied -- twelve v_mov per group before, which
+    // cost MFMA time one for one (the f32 MFMA shares the vector pipe).
     load(a, b);
-    for (int grp = 0; grp < ngrp; ++grp) {
-        load(an, bn);  // operands of the next group are fetched while this group's 8 MFMAs run
-#pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) {
-            accR = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s4], b[s4].x, accR, 0, 0, 0);
-            accI = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s4], b[s4].y, accI, 0, 0, 0);
-        }
-#pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) {
-            a[s4] = an[s4];
-            b[s4] = bn[s4];
-        }
+    int grp = 0;
+    for (; grp + 2 <= ngrp; grp += 2) {
+        load(an, bn);
+        mfma8(a, b);
+        load(a, b);
+        mfma8(an, bn);
     }
-#pragma unroll
-    for (int s4 = 0; s4 < 3; ++s4)
-        if (s4 < tail) {
-            accR = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s4], b[s4].x, accR, 0, 0, 0);
-            accI = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s4], b[s4].y, accI, 0, 0, 0);
-        }
+    if (grp < ngrp) {
+        load(an, bn);
+        mfma8(a, b);
+        mfma_tail(an, bn);
+    } else
+        mfma_tail(a, b);
 }
 
 #define MFMA_ROT_K 4   // 16-B loads in flight per lane in the rotating staging loop (8: 145 VGPRs, 3 waves per SIMD)
