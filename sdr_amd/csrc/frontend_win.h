@@ -327,9 +327,11 @@ __device__ __forceinline__ void win_tile(const FrontParams& P, const int tile, c
 }
 
 // blockDim.x = T (64 or 256), P.D == 1, real taps, P.tile_out = T*WIN_R - q; one tile per workgroup.
-// (A workgroup walking 2..16 consecutive tiles was measured and dropped: no faster at any count -- the
-// kernel is bound by its VALU instruction count, not by workgroup dispatch -- and the loop-carried
-// values cost 40 VGPRs, i.e. two resident waves per SIMD.)
+// (A workgroup walking 2..16 consecutive tiles was measured twice and dropped.  Round 2a: no faster at any
+// count.  Round 2b, with two sample buffers, the next tile's DMA in flight during the FIR and LDS-only barriers
+// in the epilogue so that nothing waits for it: 0.339 ms against 0.285 on the TFA shape, 0.308 against 0.251 on
+// the R shape -- two buffers are 43 KB of LDS, 3 workgroups per CU instead of 7, and this kernel lives on its
+// 28 resident waves hiding each other's LDS and fma latencies, not on prefetch.)
 template <bool CPLX>
 __global__ void __launch_bounds__(256) k_frontend_win(FrontParams P)
 {
