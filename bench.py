@@ -32,6 +32,10 @@ N_PER_CAPTURE = 1 << 18
 DECIM = 50
 F_OFF = 100e3
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# sdr_set_overlap: the back end of step k (one workgroup per capture or row, latency bound) runs on the handles'
+# second stream beside the front end of step k+1 (HBM or FMA bound).  Every step still does all of its work, and the
+# timed region ends with a device-wide synchronize.  SDR_BENCH_OVERLAP=0 gives the one-stream timing.
+OVERLAP = os.environ.get("SDR_BENCH_OVERLAP", "1") != "0"
 FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32 vector peak = f32-input MFMA peak
 BYTES_PER_SAMPLE = 8.0 + 1.0 / DECIM  # complex64 in + sliced byte out
 
@@ -253,6 +257,7 @@ def r_shape_workload(torch, dev, skip_cpu, ncap=64, n=1 << 19, fs=2e6, steps=20)
     c = chain.Chain(fs, decim=1, taps=taps, keep_n=100, decoder=chain.DEC_TS33C, max_batch=ncap, max_frames=4,
                     max_samples=n)
     c.set_stream(torch.cuda.current_stream().cuda_stream)
+    c.set_overlap(OVERLAP)
     for _ in range(3):
         c.batch_process(iq)
     torch.cuda.synchronize()
@@ -314,6 +319,7 @@ def cu8_workload(torch, dev, iq, pkts, taps, steps=20):
     c = chain.Chain(FS, decim=DECIM, center_freq=F_OFF, taps=taps, decoder=chain.DEC_TS33C, max_batch=ncap,
                     max_frames=4, max_samples=n, input_format="cu8")
     c.set_stream(torch.cuda.current_stream().cuda_stream)
+    c.set_overlap(OVERLAP)
     for _ in range(3):
         c.batch_process(u8)
     torch.cuda.synchronize()
@@ -382,6 +388,7 @@ def tfa_fsk_workload(torch, dev, skip_cpu, ncap=64, n=1 << 20, fs=2e6, dev_hz=60
     c = chain.Chain(fs, decim=1, taps=taps, demod=chain.DEMOD_QUAD, demod_gain=gain, thr=(-0.2, 0.2),
                     decoder=chain.DEC_TFA_GRC, max_batch=ncap, max_frames=32, max_samples=n)
     c.set_stream(torch.cuda.current_stream().cuda_stream)
+    c.set_overlap(OVERLAP)
     for _ in range(3):
         c.batch_process(iq)
     torch.cuda.synchronize()
@@ -485,6 +492,7 @@ def mixed_emitters_workload(torch, dev, skip_cpu, ncap=1250, n=N_PER_CAPTURE, fs
     c = chain.Chain(fs, decim=D, center_freq=F_OFF, taps=taps, decoder=chain.DEC_SOMFY, max_batch=ncap, max_frames=8,
                     max_samples=n)
     c.set_stream(torch.cuda.current_stream().cuda_stream)
+    c.set_overlap(OVERLAP)
     decs = (chain.DEC_SOMFY, chain.DEC_BERNER, chain.DEC_MUMBI)
 
     def step(collect=None):
@@ -613,6 +621,7 @@ def pfb_workload(torch, dev, skip_cpu, n=1 << 26, fs=20e6, steps=10):
     c = chain.Chain(fs, taps=taps, keep_n=keep, decoder=chain.DEC_TS33C, decoder_rate=rate, max_samples=n,
                     max_frames=64, channels=M)
     c.set_stream(torch.cuda.current_stream().cuda_stream)
+    c.set_overlap(OVERLAP)
     x = iq.reshape(1, n, 2)
     rules = (chain.DEC_SOMFY, chain.DEC_BERNER, chain.DEC_MUMBI)
 
@@ -817,12 +826,13 @@ def main():
     c = chain.Chain(FS, decim=DECIM, center_freq=F_OFF, taps=taps, decoder=chain.DEC_TS33C, max_batch=ncap,
                     max_frames=max_frames, max_samples=N_PER_CAPTURE)
     c.set_stream(torch.cuda.current_stream().cuda_stream)
+    c.set_overlap(OVERLAP)
     rec = torch.zeros(ncap * max_frames * 96, dtype=torch.uint8, device=dev)
     cnt = torch.zeros(ncap, dtype=torch.int32, device=dev)
     if use_dist:
         # The frame gather of step k runs on its own stream while the front end of step k+1 runs on the
-        # main one: frame records are exported (a small copy kernel on the main stream) into one of two
-        # buffer pairs, the RCCL all_gather of that pair is queued behind an event on the side stream,
+        # main one: frame records are exported (a small copy kernel on the stream results are ordered on) into one
+        # of two buffer pairs, the RCCL all_gather of that pair is queued behind an event on the side stream,
         # and a pair is reused only after its gather has finished.
         comm = torch.cuda.Stream(device=dev)
         recs, cnts = [rec, torch.zeros_like(rec)], [cnt, torch.zeros_like(cnt)]
@@ -832,15 +842,17 @@ def main():
         ev_gathered = [torch.cuda.Event() for _ in range(2)]
     kstep = [0]
 
+    # the stream the exported records are ordered on: the handle's result stream when batches overlap
+    res_stream = torch.cuda.ExternalStream(c.result_stream(), device=dev) if OVERLAP else torch.cuda.current_stream()
+
     def step():
         c.batch_process(iq)
         if use_dist:
             b = kstep[0] & 1
             kstep[0] += 1
-            main_stream = torch.cuda.current_stream()
-            main_stream.wait_event(ev_gathered[b])
+            res_stream.wait_event(ev_gathered[b])
             c.export_frames(recs[b], cnts[b])
-            ev_exported[b].record(main_stream)
+            ev_exported[b].record(res_stream)
             with torch.cuda.stream(comm):
                 comm.wait_event(ev_exported[b])
                 sdist.gather_frames(recs[b], cnts[b], world, all_recs[b], all_cnts[b])

@@ -189,6 +189,23 @@ SDR_API int sdr_fetch_squelch_counts(sdr_handle* h, int32_t* out, size_t cap, si
  * current stream; NULL = the handle's own stream. */
 SDR_API int sdr_set_stream(sdr_handle* h, void* hip_stream);
 SDR_API int sdr_synchronize(sdr_handle* h);
+
+/* Overlapped batches (throughput mode; no counterpart in the reference, whose flowgraph runs its blocks as
+ * concurrent threads -- this is the same pipelining between the filter blocks and the decoder block, on one
+ * GPU).  With on != 0 a second, library-owned "result stream" takes the back end (run-length + decoders) of
+ * every sdr_batch_process and the device-side result readers (sdr_redecode, sdr_redecode_multi,
+ * sdr_export_frames, sdr_export_bits), so that the latency-bound back end of batch k runs beside the
+ * HBM-bound front end of batch k+1; front ends alternate between two sets of sliced rows.  Results and state
+ * are identical to on == 0.  Ordering: inputs are read in the order of the handle's stream, as before; what
+ * the exports write is ordered on sdr_result_stream(h) (record an event there, or call sdr_synchronize).
+ * Every other entry point (host fetches, streaming calls, setters, sdr_seek, sdr_batch_process_static) first
+ * makes the handle's stream wait for the result stream and then behaves as with on == 0, so it ends the
+ * overlap for that step.  A batch behind a gating squelch is not overlapped.  Costs a second copy of the
+ * sliced rows and tile summaries.  Calls on one handle stay serialised by the caller. */
+SDR_API int sdr_set_overlap(sdr_handle* h, int on);
+/* hipStream_t (as void*) that device-side results are ordered on: the result stream while sdr_set_overlap is
+ * on, else the handle's stream. */
+SDR_API void* sdr_result_stream(sdr_handle* h);
 SDR_API const char* sdr_last_error(sdr_handle* h);
 
 /* ---- streaming entry points (state carried in the handle) -----------------

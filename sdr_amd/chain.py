@@ -145,6 +145,15 @@ class Chain(object):
     def synchronize(self):
         _lib.check(self._h, self._L.sdr_synchronize(self._h))
 
+    def set_overlap(self, on=True):
+        """sdr_set_overlap: run the back end of each batch (and redecode*/export_*) on a second stream beside
+        the next batch's front end.  Results are the same; device-side exports are ordered on result_stream()."""
+        _lib.check(self._h, self._L.sdr_set_overlap(self._h, int(bool(on))))
+
+    def result_stream(self):
+        """hipStream_t (int) that device-side results are ordered on (torch.cuda.ExternalStream takes it)."""
+        return int(self._L.sdr_result_stream(self._h) or 0)
+
     # -- data path
     def _nsamp(self, keep, dev):
         """complex samples in a 1-D stream argument"""

@@ -164,6 +164,8 @@ __global__ void __launch_bounds__(BK_THREADS, 6) k_backend(BackParams P)
         st->n_frames = 0;
         if (P.phase_sel != 2) st->first_evt = -1;   // phase_sel 2 follows a phase-0 launch that has set it
     }
+    // the carry launch of a long row clears the row's piece header for the launches behind it
+    if (P.phase_sel == 1 && P.pieces_hdr && tid < 8) P.pieces_hdr[(long long)cap * 8 + tid] = 0;
     __syncthreads();
 
     // ---- phase 0: hysteresis carries --------------------------------------

@@ -143,6 +143,11 @@ static int pfb_batch(sdr_handle* h, const void* iq, size_t n, size_t stride, int
     if (stride < n) return fail(h, SDR_E_ARG, "sdr_batch_process: stride < n_per_capture");
     if (h->in_fmt != SDR_IN_FC32) return fail(h, SDR_E_ARG, "channelizer: complex64 input only");
     (void)hipSetDevice(h->device);
+    if (h->overlap) {
+        int r = ov_next_buffers(h);
+        if (r) return r;
+    }
+    OvScope ovs(h, h->overlap);
     const float2* x = (const float2*)iq;
     if (!is_dev) {
         int r = ensure_iq_staging(h, (size_t)ncap * stride);
@@ -249,6 +254,7 @@ extern "C" int sdr_redecode(sdr_handle* h, int decoder, double decoder_rate)
     if (h->last_ncap < 1) return fail(h, SDR_E_ARG, "sdr_redecode: no batch processed yet");
     if (h->last_bits_off != 0 || h->raw_n != 0) return fail(h, SDR_E_ARG, "sdr_redecode: only after sdr_batch_process");
     (void)hipSetDevice(h->device);
+    OvScope ovs(h, h->overlap);   // back-end work only: on the result stream when batches overlap
     const int keep_dec = h->cfg.decoder;
     const double keep_rate = h->dec_rate;
     h->cfg.decoder = decoder;
@@ -284,9 +290,11 @@ extern "C" int sdr_redecode_multi(sdr_handle* h, const int32_t* decoders, int n,
     if (h->last_ncap < 1) return fail(h, SDR_E_ARG, "sdr_redecode_multi: no batch processed yet");
     if (h->last_bits_off != 0 || h->raw_n != 0) return fail(h, SDR_E_ARG, "sdr_redecode_multi: only after sdr_batch_process");
     (void)hipSetDevice(h->device);
+    OvScope ovs(h, h->overlap);   // as sdr_redecode
     const int rows = h->last_ncap;
     const long long need = (long long)rows * n;
     if (need > h->m_cap) {
+        OV_JOIN(h);
         HIPCHK(h, hipStreamSynchronize(h->stream));
         for (void* p : {(void*)h->d_m_cur, (void*)h->d_m_st, (void*)h->d_m_frames})
             if (p) (void)hipFree(p);
@@ -335,19 +343,24 @@ extern "C" int sdr_redecode_multi(sdr_handle* h, const int32_t* decoders, int n,
     for (int i = 0; i < n; ++i)
         if (is_stream_decoder(decoders[i]) && !((double)Bp.nb * 1e6 / rate > decoder_reset_limit(decoders[i])))
             return fail(h, SDR_E_ARG, "sdr_redecode_multi: rows shorter than a stream decoder's reset limit");
-    if (h->profile) {
-        HIPCHK(h, hipEventRecord(h->pev[3 * (h->pcount % SDR_PROF_RING)], h->stream));
-        HIPCHK(h, hipEventRecord(h->pev[3 * (h->pcount % SDR_PROF_RING) + 1], h->stream));
+    hipStream_t bs;
+    {
+        int rb = result_stream_begin(h, &bs);
+        if (rb) return rb;
     }
-    hipLaunchKernelGGL(k_backend, dim3((unsigned)need), dim3(BK_THREADS), 0, h->stream, Bp);
+    if (h->profile) {
+        HIPCHK(h, hipEventRecord(h->pev[3 * (h->pcount % SDR_PROF_RING)], bs));
+        HIPCHK(h, hipEventRecord(h->pev[3 * (h->pcount % SDR_PROF_RING) + 1], bs));
+    }
+    hipLaunchKernelGGL(k_backend, dim3((unsigned)need), dim3(BK_THREADS), 0, bs, Bp);
     HIPCHK(h, hipGetLastError());
     if (h->profile) {
-        HIPCHK(h, hipEventRecord(h->pev[3 * (h->pcount % SDR_PROF_RING) + 2], h->stream));
+        HIPCHK(h, hipEventRecord(h->pev[3 * (h->pcount % SDR_PROF_RING) + 2], bs));
         h->pcount++;
     }
     h->m_ndec = n;
     h->m_rows = rows;
-    return SDR_OK;
+    return result_stream_end(h);
 }
 
 // frames of decoder number k (0-based position in the list) of the last sdr_redecode_multi
@@ -355,6 +368,7 @@ extern "C" int sdr_fetch_frames_multi(sdr_handle* h, int k, sdr_frame* outp, siz
 {
     if (!h || !n || k < 0 || k >= h->m_ndec) return fail(h, SDR_E_ARG, "sdr_fetch_frames_multi: bad argument");
     (void)hipSetDevice(h->device);
+    OV_JOIN(h);
     HIPCHK(h, hipStreamSynchronize(h->stream));
     const int B = h->m_rows;
     *n = 0;

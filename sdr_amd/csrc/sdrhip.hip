@@ -132,6 +132,20 @@ struct sdr_handle {
     bool profile = false;
     std::vector<hipEvent_t> pev;   // 3 events per slot: front start, front end/back start, back end
     unsigned long long pcount = 0;
+
+    // overlapped batches (sdr_set_overlap): the back end of a batch, and what reads its results on the device
+    // (sdr_redecode*, sdr_export_*), run on a second stream beside the front end of the next batch.  The front
+    // end alternates between two (sliced bytes, tile summaries) pairs; everything else the back end touches
+    // is only ever touched on that second stream, in order.
+    bool overlap = false;
+    hipStream_t bstream = nullptr;
+    bool ov_call = false;        // the current call puts its back-end side on bstream
+    bool ov_pending = false;     // bstream holds work h->stream has not been ordered behind
+    int ov_sel = 0, ov_last = 0; // pair the last batch wrote; pair whose event was recorded last
+    int8_t* d_bits2 = nullptr;
+    TileSum* d_tsum2 = nullptr;
+    hipEvent_t ov_front = nullptr, ov_back[2] = {nullptr, nullptr};
+    bool ov_back_rec[2] = {false, false};
 };
 
 static thread_local std::string g_err;
@@ -149,6 +163,61 @@ static int fail(sdr_handle* h, int code, const std::string& msg)
         if (e_ != hipSuccess)                                                                 \
             return fail(h, SDR_E_HIP, std::string(#call) + ": " + hipGetErrorString(e_));     \
     } while (0)
+
+// ------------------------------------------------------------------ overlapped batches
+// Entry points that read or replace what a back end writes call ov_join first: h->stream waits for the last
+// event of the result stream, after which the handle behaves as if it had one stream.
+static int ov_join(sdr_handle* h)
+{
+    if (h && h->ov_pending) {
+        (void)hipSetDevice(h->device);
+        HIPCHK(h, hipStreamWaitEvent(h->stream, h->ov_back[h->ov_last], 0));
+        h->ov_pending = false;
+    }
+    return SDR_OK;
+}
+#define OV_JOIN(h)              \
+    do {                        \
+        int j_ = ov_join(h);    \
+        if (j_) return j_;      \
+    } while (0)
+
+struct OvScope {   // marks the calls whose back-end side goes to the result stream
+    sdr_handle* h;
+    bool prev;
+    OvScope(sdr_handle* h_, bool on) : h(h_), prev(h_->ov_call) { h->ov_call = on; }
+    ~OvScope() { h->ov_call = prev; }
+};
+
+// the stream the back-end side of this call runs on; inside an overlapped call it is ordered behind
+// everything queued on h->stream so far (the front end just launched)
+static int result_stream_begin(sdr_handle* h, hipStream_t* bs)
+{
+    *bs = h->stream;
+    if (!h->ov_call) return SDR_OK;
+    HIPCHK(h, hipEventRecord(h->ov_front, h->stream));
+    HIPCHK(h, hipStreamWaitEvent(h->bstream, h->ov_front, 0));
+    *bs = h->bstream;
+    return SDR_OK;
+}
+static int result_stream_end(sdr_handle* h)
+{
+    if (!h->ov_call) return SDR_OK;
+    HIPCHK(h, hipEventRecord(h->ov_back[h->ov_sel], h->bstream));
+    h->ov_back_rec[h->ov_sel] = true;
+    h->ov_last = h->ov_sel;
+    h->ov_pending = true;
+    return SDR_OK;
+}
+// the front end of an overlapped batch writes the pair the back end before last read
+static int ov_next_buffers(sdr_handle* h)
+{
+    std::swap(h->d_bits, h->d_bits2);
+    std::swap(h->d_tsum, h->d_tsum2);
+    h->ov_sel ^= 1;
+    if (h->ov_back_rec[h->ov_sel]) HIPCHK(h, hipStreamWaitEvent(h->stream, h->ov_back[h->ov_sel], 0));
+    return SDR_OK;
+}
 
 // ------------------------------------------------------------------ firdes
 // gr-filter/lib/firdes.cc low_pass + gr-fft/lib/window.cc (GNU Radio 3.7.11),
@@ -479,7 +548,14 @@ extern "C" int sdr_destroy(sdr_handle* h)
         h->pre = nullptr;
     }
     if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
-    void* ptrs[] = {h->d_rtaps, h->d_post_rtaps, h->d_nco_tab, h->d_atan_tab, h->d_pow, h->d_log2, h->d_iq,
+    if (h->bstream) {
+        (void)hipStreamSynchronize(h->bstream);
+        (void)hipStreamSynchronize(h->stream);
+        (void)hipStreamDestroy(h->bstream);
+        for (hipEvent_t e : {h->ov_front, h->ov_back[0], h->ov_back[1]})
+            if (e) (void)hipEventDestroy(e);
+    }
+    void* ptrs[] = {h->d_bits2, h->d_tsum2, h->d_rtaps, h->d_post_rtaps, h->d_nco_tab, h->d_atan_tab, h->d_pow, h->d_log2, h->d_iq,
                     h->d_hist[0], h->d_hist[1], h->d_bits, h->d_tap, h->d_tap2, h->d_tsum, h->d_runs, h->d_runs_seg, h->d_seg_cnt, h->d_runs_n, h->d_pieces_hdr,
                     h->d_cur, h->d_st, h->d_rule, h->d_frames, h->d_m_cur, h->d_m_st, h->d_m_frames, h->d_sq_y, h->d_sq_z, h->d_sq_cnt, h->d_sq_st,
                     h->d_post_hist[0], h->d_post_hist[1], h->d_pack, h->d_pfb_taps, h->d_pfb_tw};
@@ -624,6 +700,7 @@ extern "C" int sdr_set_taps(sdr_handle* h, const float* taps, int n, int is_comp
 {
     if (!h || !taps || n < 1 || n > 65536) return fail(h, SDR_E_ARG, "sdr_set_taps: bad argument");
     (void)hipSetDevice(h->device);
+    OV_JOIN(h);
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->proto_taps.assign(taps, taps + (is_complex ? 2 * n : n));
     h->proto_complex = is_complex != 0;
@@ -642,6 +719,7 @@ extern "C" int sdr_set_post_taps(sdr_handle* h, const float* taps, int n)
     if (!h || !taps || n < 1 || n != h->cfg.post_ntaps)
         return fail(h, SDR_E_ARG, "sdr_set_post_taps: n must equal cfg.post_ntaps");
     (void)hipSetDevice(h->device);
+    OV_JOIN(h);
     std::vector<float> rt(n);
     for (int k = 0; k < n; ++k) rt[n - 1 - k] = taps[k];
     if (!h->d_post_rtaps) HIPCHK(h, dev_alloc((void**)&h->d_post_rtaps, n * sizeof(float)));
@@ -659,6 +737,7 @@ extern "C" int sdr_set_prefilter(sdr_handle* h, const float* taps, int n, int de
 {
     if (!h || !taps || n < 1 || n > 65536 || decim < 1) return fail(h, SDR_E_ARG, "sdr_set_prefilter: bad argument");
     (void)hipSetDevice(h->device);
+    OV_JOIN(h);
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (h->pre) {
         sdr_destroy(h->pre);
@@ -697,6 +776,7 @@ extern "C" int sdr_set_input_format(sdr_handle* h, int fmt)
     if (!h || (fmt != SDR_IN_FC32 && fmt != SDR_IN_CU8)) return fail(h, SDR_E_ARG, "sdr_set_input_format: unknown format");
     if (h->prerotate) return fail(h, SDR_E_ARG, "sdr_set_input_format: not available on this chain");
     (void)hipSetDevice(h->device);
+    OV_JOIN(h);
     HIPCHK(h, hipStreamSynchronize(h->stream));
     sdr_handle* t = h->pre ? h->pre : h;
     t->in_fmt = fmt;
@@ -711,6 +791,7 @@ extern "C" int sdr_set_squelch(sdr_handle* h, double threshold_db, double alpha,
     if (h->cfg.post_ntaps > 0 || h->cfg.demod == SDR_DEMOD_NONE || h->prerotate || h->skip_slice)
         return fail(h, SDR_E_ARG, "sdr_set_squelch: needs a MAG2/QUAD chain without a post-demod filter");
     (void)hipSetDevice(h->device);
+    OV_JOIN(h);
     HIPCHK(h, hipStreamSynchronize(h->stream));
     const long long B = h->cfg.max_batch;
     if (!h->d_sq_y) {
@@ -740,8 +821,34 @@ extern "C" int sdr_set_stream(sdr_handle* h, void* s)
 extern "C" int sdr_synchronize(sdr_handle* h)
 {
     if (!h) return SDR_E_ARG;
+    OV_JOIN(h);
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return SDR_OK;
+}
+
+extern "C" int sdr_set_overlap(sdr_handle* h, int on)
+{
+    if (!h) return SDR_E_ARG;
+    (void)hipSetDevice(h->device);
+    OV_JOIN(h);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (on && !h->bstream) {
+        const size_t B = (size_t)h->cfg.max_batch;
+        HIPCHK(h, hipStreamCreateWithFlags(&h->bstream, hipStreamNonBlocking));
+        HIPCHK(h, hipEventCreateWithFlags(&h->ov_front, hipEventDisableTiming));
+        for (int i = 0; i < 2; ++i) HIPCHK(h, hipEventCreateWithFlags(&h->ov_back[i], hipEventDisableTiming));
+        HIPCHK(h, dev_alloc((void**)&h->d_bits2, B * (size_t)h->bits_stride));
+        HIPCHK(h, hipMemset(h->d_bits2, 0, B * (size_t)h->bits_stride));
+        HIPCHK(h, dev_alloc((void**)&h->d_tsum2, B * (size_t)h->tsum_stride * sizeof(TileSum)));
+    }
+    h->overlap = on != 0;
+    return SDR_OK;
+}
+
+extern "C" void* sdr_result_stream(sdr_handle* h)
+{
+    if (!h) return nullptr;
+    return (void*)(h->overlap ? h->bstream : h->stream);
 }
 
 extern "C" int sdr_timer_start(sdr_handle* h)
@@ -1001,6 +1108,11 @@ static int launch_back(sdr_handle* h, int ncap, const CallGeom& g, long long pat
         }
         return SDR_OK;
     }
+    hipStream_t bs;
+    {
+        int rb = result_stream_begin(h, &bs);
+        if (rb) return rb;
+    }
     BackParams Bp;
     memset(&Bp, 0, sizeof Bp);
     Bp.bits = h->d_bits;
@@ -1039,7 +1151,7 @@ static int launch_back(sdr_handle* h, int ncap, const CallGeom& g, long long pat
     const bool full_pass = run_decoder && c.decoder != SDR_DEC_NONE && !Bp.nout_var;
     if (h->reuse_next && h->runs_valid && full_pass && !h->no_reuse) {
         Bp.reuse_runs = 1;
-        hipLaunchKernelGGL(k_backend, dim3(ncap), dim3(BK_THREADS), 0, h->stream, Bp);
+        hipLaunchKernelGGL(k_backend, dim3(ncap), dim3(BK_THREADS), 0, bs, Bp);
     } else if (h->d_runs_seg && !Bp.nout_var && run_decoder && c.decoder != SDR_DEC_NONE && nb_total >= h->seg_min_row &&
         !h->no_seg) {
         // long rows: carries first (they patch the bytes), then the run starts of every 64-KiB-or-more
@@ -1052,28 +1164,27 @@ static int launch_back(sdr_handle* h, int ncap, const CallGeom& g, long long pat
         Bp.runs_seg = h->d_runs_seg;
         Bp.seg_cnt = h->d_seg_cnt;
         Bp.phase_sel = 1;
-        hipLaunchKernelGGL(k_backend, dim3(ncap), dim3(BK_THREADS), 0, h->stream, Bp);
-        hipLaunchKernelGGL(k_runs_seg, dim3(Bp.nseg, ncap), dim3(BK_THREADS), 0, h->stream, Bp);
+        const bool pieces = is_stream_decoder(c.decoder) && !h->no_pieces;
+        if (pieces) {   // the phase-1 launch zeroes the piece headers
+            Bp.pieces_b = h->d_runs_seg;
+            Bp.pieces_hdr = h->d_pieces_hdr;
+        }
+        hipLaunchKernelGGL(k_backend, dim3(ncap), dim3(BK_THREADS), 0, bs, Bp);
+        hipLaunchKernelGGL(k_runs_seg, dim3(Bp.nseg, ncap), dim3(BK_THREADS), 0, bs, Bp);
         Bp.phase_sel = 2;
         Bp.tsum = nullptr;
         Bp.fresh = 0;
-        const bool pieces = is_stream_decoder(c.decoder) && !h->no_pieces;
-        if (pieces) {
-            Bp.pieces_b = h->d_runs_seg;
-            Bp.pieces_hdr = h->d_pieces_hdr;
-            HIPCHK(h, hipMemsetAsync(h->d_pieces_hdr, 0, (size_t)ncap * 8 * sizeof(int32_t), h->stream));
-        }
-        hipLaunchKernelGGL(k_backend, dim3(ncap), dim3(BK_THREADS), 0, h->stream, Bp);
-        if (pieces) hipLaunchKernelGGL(k_decode_pieces, dim3(256, ncap), dim3(64), 0, h->stream, Bp);
+        hipLaunchKernelGGL(k_backend, dim3(ncap), dim3(BK_THREADS), 0, bs, Bp);
+        if (pieces) hipLaunchKernelGGL(k_decode_pieces, dim3(256, ncap), dim3(64), 0, bs, Bp);
     } else
-        hipLaunchKernelGGL(k_backend, dim3(ncap), dim3(BK_THREADS), 0, h->stream, Bp);
+        hipLaunchKernelGGL(k_backend, dim3(ncap), dim3(BK_THREADS), 0, bs, Bp);
     HIPCHK(h, hipGetLastError());
     if (!Bp.reuse_runs) h->runs_valid = full_pass;
     if (h->profile) {
-        HIPCHK(h, hipEventRecord(h->pev[3 * (h->pcount % SDR_PROF_RING) + 2], h->stream));
+        HIPCHK(h, hipEventRecord(h->pev[3 * (h->pcount % SDR_PROF_RING) + 2], bs));
         h->pcount++;
     }
-    return SDR_OK;
+    return result_stream_end(h);
 }
 
 static void fill_geom(const sdr_handle* h, long long nout, long long in0, long long keep_c0, CallGeom& g,
@@ -1184,6 +1295,14 @@ extern "C" int sdr_batch_process(sdr_handle* h, const void* iq, size_t n, size_t
         return fail(h, SDR_E_CAPACITY, "sdr_batch_process: batch larger than the handle was created for");
     if (stride < n) return fail(h, SDR_E_ARG, "sdr_batch_process: stride < n_per_capture");
     (void)hipSetDevice(h->device);
+    // behind a gating squelch the back end reads per-capture counts the next front end would overwrite
+    const bool ov = h->overlap && !h->squelch_on;
+    if (ov) {
+        int r = ov_next_buffers(h);
+        if (r) return r;
+    } else
+        OV_JOIN(h);
+    OvScope ovs(h, ov);
     const float2* x = (const float2*)iq;
     if (!is_dev) {
         int r = ensure_iq_staging(h, (size_t)ncap * stride);
@@ -1268,6 +1387,7 @@ static int stream_decode_step(sdr_handle* h, const CallGeom& g, const float2* x,
 extern "C" int sdr_process_iq(sdr_handle* h, const void* iq, size_t n, int is_dev, sdr_out* out)
 {
     if (!h || (!iq && n)) return fail(h, SDR_E_ARG, "sdr_process_iq: bad argument");
+    OV_JOIN(h);
     if (h->pfb_M) return pfb_stream(h, iq, n, is_dev, out);
     if (h->pre) {
         int r = sdr_process_iq(h->pre, iq, n, is_dev, nullptr);
@@ -1358,6 +1478,7 @@ extern "C" int sdr_process_bits(sdr_handle* h, const int8_t* bits, size_t n, int
     if (!h || (!bits && n)) return fail(h, SDR_E_ARG, "sdr_process_bits: bad argument");
     if (h->cfg.decoder == SDR_DEC_NONE) return fail(h, SDR_E_ARG, "sdr_process_bits: no decoder configured");
     (void)hipSetDevice(h->device);
+    OV_JOIN(h);
     const long long off = is_stream_decoder(h->cfg.decoder) ? h->raw_n : 0;
     if (off + (long long)n > h->bits_stride) return fail(h, SDR_E_CAPACITY, "sdr_process_bits: chunk too large");
     if (n)
@@ -1425,6 +1546,7 @@ extern "C" int sdr_fetch_frames(sdr_handle* h, sdr_frame* outp, size_t cap, size
 {
     if (!h || !n) return fail(h, SDR_E_ARG, "sdr_fetch_frames: bad argument");
     (void)hipSetDevice(h->device);
+    OV_JOIN(h);
     HIPCHK(h, hipStreamSynchronize(h->stream));
     const int B = h->last_ncap;
     *n = 0;
@@ -1453,6 +1575,7 @@ extern "C" int sdr_fetch_bits(sdr_handle* h, int8_t* outp, size_t cap, size_t* n
 {
     if (!h || !n) return fail(h, SDR_E_ARG, "sdr_fetch_bits: bad argument");
     (void)hipSetDevice(h->device);
+    OV_JOIN(h);
     HIPCHK(h, hipStreamSynchronize(h->stream));
     const size_t total = (size_t)h->last_ncap * (size_t)h->last_nb;
     *n = total;
@@ -1466,6 +1589,7 @@ extern "C" int sdr_fetch_demod(sdr_handle* h, float* outp, size_t cap, size_t* n
     if (!h || !n) return fail(h, SDR_E_ARG, "sdr_fetch_demod: bad argument");
     if (!h->d_tap) return fail(h, SDR_E_ARG, "sdr_fetch_demod: handle created without tap_demod");
     (void)hipSetDevice(h->device);
+    OV_JOIN(h);
     HIPCHK(h, hipStreamSynchronize(h->stream));
     const size_t w = (size_t)h->last_nout * (h->cfg.demod == SDR_DEMOD_NONE ? 2 : 1);
     const size_t total = (size_t)h->last_ncap * w;
@@ -1480,6 +1604,7 @@ extern "C" int sdr_fetch_squelch_counts(sdr_handle* h, int32_t* outp, size_t cap
     if (!h || !n) return fail(h, SDR_E_ARG, "sdr_fetch_squelch_counts: bad argument");
     if (!h->squelch_on) return fail(h, SDR_E_ARG, "sdr_fetch_squelch_counts: no squelch configured");
     (void)hipSetDevice(h->device);
+    OV_JOIN(h);
     HIPCHK(h, hipStreamSynchronize(h->stream));
     *n = (size_t)h->last_ncap;
     if (!outp || cap < *n || *n == 0) return SDR_OK;
@@ -1491,6 +1616,7 @@ extern "C" int sdr_decoder_state(sdr_handle* h, int32_t state[4])
 {
     if (!h || !state) return SDR_E_ARG;
     (void)hipSetDevice(h->device);
+    OV_JOIN(h);
     HIPCHK(h, hipStreamSynchronize(h->stream));
     DecState s;
     HIPCHK(h, hipMemcpy(&s, h->d_st, sizeof s, hipMemcpyDeviceToHost));
@@ -1518,6 +1644,7 @@ extern "C" int sdr_profile_read(sdr_handle* h, float* front_ms, float* back_ms, 
 {
     if (!h || !n) return SDR_E_ARG;
     (void)hipSetDevice(h->device);
+    OV_JOIN(h);
     HIPCHK(h, hipStreamSynchronize(h->stream));
     unsigned long long have = h->pcount < SDR_PROF_RING ? h->pcount : SDR_PROF_RING;
     if ((unsigned long long)cap < have) have = cap;
@@ -1561,10 +1688,17 @@ extern "C" int sdr_export_frames(sdr_handle* h, void* frames_dev, size_t frames_
     long long total = (long long)B * h->cfg.max_frames * (sizeof(sdr_frame) / 4);
     int blocks = (int)((total + 255) / 256);
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(k_export_frames, dim3(blocks), dim3(256), 0, h->stream, h->d_frames, h->d_st, B,
+    // with sdr_set_overlap on, device-side result readers run on the result stream (sdr_result_stream)
+    OvScope ovs(h, h->overlap);
+    hipStream_t bs;
+    {
+        int rb = result_stream_begin(h, &bs);
+        if (rb) return rb;
+    }
+    hipLaunchKernelGGL(k_export_frames, dim3(blocks), dim3(256), 0, bs, h->d_frames, h->d_st, B,
                        h->cfg.max_frames, (sdr_frame*)frames_dev, (int32_t*)counts_dev);
     HIPCHK(h, hipGetLastError());
-    return SDR_OK;
+    return result_stream_end(h);
 }
 
 // ------------------------------------------------------------------ segments
@@ -1638,6 +1772,7 @@ static int seek_warm(sdr_handle* h, uint64_t abs_index, const void* halo, size_t
 extern "C" int sdr_seek(sdr_handle* h, uint64_t abs_index, const void* halo, size_t n_halo, int is_dev)
 {
     if (!h) return fail(h, SDR_E_ARG, "sdr_seek: null handle");
+    OV_JOIN(h);
     if (h->squelch_on)
         return fail(h, SDR_E_ARG, "sdr_seek: a squelch chain cannot be positioned from a halo (the power average is an IIR "
                                   "and the gate makes output positions data dependent)");
@@ -1668,6 +1803,7 @@ extern "C" int sdr_segment_info_get(sdr_handle* h, sdr_segment_info* info)
 {
     if (!h || !info) return fail(h, SDR_E_ARG, "sdr_segment_info_get: null argument");
     (void)hipSetDevice(h->device);
+    OV_JOIN(h);
     HIPCHK(h, hipStreamSynchronize(h->stream));
     DecState s;
     HIPCHK(h, hipMemcpy(&s, h->d_st, sizeof s, hipMemcpyDeviceToHost));
@@ -1692,6 +1828,7 @@ extern "C" int sdr_segment_info_rows(sdr_handle* h, sdr_segment_info* info, size
 {
     if (!h || !n) return fail(h, SDR_E_ARG, "sdr_segment_info_rows: null argument");
     (void)hipSetDevice(h->device);
+    OV_JOIN(h);
     HIPCHK(h, hipStreamSynchronize(h->stream));
     const size_t rows = (size_t)h->last_ncap;
     *n = rows;
@@ -1728,6 +1865,7 @@ extern "C" int sdr_batch_process_bits(sdr_handle* h, const int8_t* bits, size_t 
         return fail(h, SDR_E_CAPACITY, "sdr_batch_process_bits: more rows or longer rows than the handle was created for");
     if (stride < n) return fail(h, SDR_E_ARG, "sdr_batch_process_bits: stride < n");
     (void)hipSetDevice(h->device);
+    OV_JOIN(h);
     if (n) {
         if (rows == 1 || (stride == n && (size_t)h->bits_stride == n))
             HIPCHK(h, hipMemcpyAsync(h->d_bits, bits, n * (size_t)rows, is_dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
@@ -1771,16 +1909,22 @@ extern "C" int sdr_export_bits(sdr_handle* h, void* bits_dev, size_t cap_bytes, 
     if (!bits_dev || cap_bytes < total) return fail(h, SDR_E_CAPACITY, "sdr_export_bits: destination too small");
     (void)hipSetDevice(h->device);
     const int8_t* src = h->d_bits + h->last_bits_off;
+    OvScope ovs(h, h->overlap);   // as sdr_export_frames
+    hipStream_t bs;
+    {
+        int rb = result_stream_begin(h, &bs);
+        if (rb) return rb;
+    }
     if (rows == 1 || (size_t)h->bits_stride == width) {
-        HIPCHK(h, hipMemcpyAsync(bits_dev, src, total, hipMemcpyDeviceToDevice, h->stream));
-        return SDR_OK;
+        HIPCHK(h, hipMemcpyAsync(bits_dev, src, total, hipMemcpyDeviceToDevice, bs));
+        return result_stream_end(h);
     }
     size_t blocks = (total + 255) / 256;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(k_pack_rows, dim3((unsigned)blocks), dim3(256), 0, h->stream, (const unsigned char*)src,
+    hipLaunchKernelGGL(k_pack_rows, dim3((unsigned)blocks), dim3(256), 0, bs, (const unsigned char*)src,
                        (size_t)h->bits_stride, width, rows, (unsigned char*)bits_dev);
     HIPCHK(h, hipGetLastError());
-    return SDR_OK;
+    return result_stream_end(h);
 }
 
 // ------------------------------------------------------------------ allocation-free batch entry point
@@ -1825,6 +1969,7 @@ extern "C" int sdr_batch_process_static(sdr_handle* h, const void* iq_dev, size_
     if (h->device < 0 || h->device >= SDR_STATIC_MAX_DEVICES || !g_scratch_ptr[h->device])
         return fail(h, SDR_E_HIP, "sdr_batch_process_static: no static scratch address for this device");
     (void)hipSetDevice(h->device);
+    OV_JOIN(h);   // this entry point stays on h->stream, whatever sdr_set_overlap says
     const sdr_chain_cfg& c = h->cfg;
     CallGeom g;
     fill_geom(h, (long long)(n / c.decim), 0, c.keep_n - 1, g, false);
