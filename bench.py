@@ -32,10 +32,14 @@ N_PER_CAPTURE = 1 << 18
 DECIM = 50
 F_OFF = 100e3
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-# sdr_set_overlap: the back end of step k (one workgroup per capture or row, latency bound) runs on the handles'
-# second stream beside the front end of step k+1 (HBM or FMA bound).  Every step still does all of its work, and the
-# timed region ends with a device-wide synchronize.  SDR_BENCH_OVERLAP=0 gives the one-stream timing.
-OVERLAP = os.environ.get("SDR_BENCH_OVERLAP", "1") != "0"
+# sdr_set_overlap: the back end of step k (latency bound: one workgroup per capture or row) runs on the handle's
+# second stream beside the front end of step k+1.  It pays where the back end's workgroups are few (the 64-row
+# workloads: -4 % R shape, -9 % TFA, -22 % channelizer step) and not where 1250 of them fill the chip's LDS (the
+# headline and cu8 batches: same step, front-end kernel 7 % slower), so those two stay on one stream.  A secondary
+# workload is timed twice, one stream first (its kernel times feed `roofline`), then overlapped (`ms_per_step`,
+# `value`); every step of either pass does all of its work and each pass ends with a device-wide synchronize.
+# SDR_BENCH_OVERLAP=0 skips the second pass.
+OVERLAP = os.environ.get("SDR_BENCH_OVERLAP", "1") != "0" and "ROCPROF_COUNTER_COLLECTION" not in os.environ   # --pmc runs one kernel at a time
 FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32 vector peak = f32-input MFMA peak
 BYTES_PER_SAMPLE = 8.0 + 1.0 / DECIM  # complex64 in + sliced byte out
 
@@ -257,7 +261,6 @@ def r_shape_workload(torch, dev, skip_cpu, ncap=64, n=1 << 19, fs=2e6, steps=20)
     c = chain.Chain(fs, decim=1, taps=taps, keep_n=100, decoder=chain.DEC_TS33C, max_batch=ncap, max_frames=4,
                     max_samples=n)
     c.set_stream(torch.cuda.current_stream().cuda_stream)
-    c.set_overlap(OVERLAP)
     for _ in range(3):
         c.batch_process(iq)
     torch.cuda.synchronize()
@@ -288,6 +291,7 @@ def r_shape_workload(torch, dev, skip_cpu, ncap=64, n=1 << 19, fs=2e6, steps=20)
                         "FMA rate (packed VALU = f32-input MFMA, 157.3 TF); the sliding-window VALU kernel issues exactly "
                         "the algorithmic fmas (the banded-Toeplitz MFMA form, SDR_FRONTEND=mfma, (15+ntaps)/ntaps times as many)"},
            "verified": "all captures decode to the transmitted packets"}
+    overlapped_pass(torch, c, lambda: c.batch_process(iq), steps, out, ncap * n)
     if not skip_cpu:
         from oracle import decoders as odec
         from oracle import dsp as odsp
@@ -319,7 +323,6 @@ def cu8_workload(torch, dev, iq, pkts, taps, steps=20):
     c = chain.Chain(FS, decim=DECIM, center_freq=F_OFF, taps=taps, decoder=chain.DEC_TS33C, max_batch=ncap,
                     max_frames=4, max_samples=n, input_format="cu8")
     c.set_stream(torch.cuda.current_stream().cuda_stream)
-    c.set_overlap(OVERLAP)
     for _ in range(3):
         c.batch_process(u8)
     torch.cuda.synchronize()
@@ -388,7 +391,6 @@ def tfa_fsk_workload(torch, dev, skip_cpu, ncap=64, n=1 << 20, fs=2e6, dev_hz=60
     c = chain.Chain(fs, decim=1, taps=taps, demod=chain.DEMOD_QUAD, demod_gain=gain, thr=(-0.2, 0.2),
                     decoder=chain.DEC_TFA_GRC, max_batch=ncap, max_frames=32, max_samples=n)
     c.set_stream(torch.cuda.current_stream().cuda_stream)
-    c.set_overlap(OVERLAP)
     for _ in range(3):
         c.batch_process(iq)
     torch.cuda.synchronize()
@@ -418,6 +420,7 @@ def tfa_fsk_workload(torch, dev, skip_cpu, ncap=64, n=1 << 20, fs=2e6, dev_hz=60
                         "note": "27 taps at decimation 1 + one fast_atan2f per sample: 108 + ~90 flop-equivalents per 9 bytes, "
                                 "bound by VALU instruction issue (profiles/r02_a_win_sq.csv), not by HBM"},
            "verified": "all captures decode to the transmitted packets (CRC-8 ok)"}
+    overlapped_pass(torch, c, lambda: c.batch_process(iq), steps, out, ncap * n)
     if not skip_cpu:
         from oracle import decoders as odec
         from oracle import dsp as odsp
@@ -492,7 +495,6 @@ def mixed_emitters_workload(torch, dev, skip_cpu, ncap=1250, n=N_PER_CAPTURE, fs
     c = chain.Chain(fs, decim=D, center_freq=F_OFF, taps=taps, decoder=chain.DEC_SOMFY, max_batch=ncap, max_frames=8,
                     max_samples=n)
     c.set_stream(torch.cuda.current_stream().cuda_stream)
-    c.set_overlap(OVERLAP)
     decs = (chain.DEC_SOMFY, chain.DEC_BERNER, chain.DEC_MUMBI)
 
     def step(collect=None):
@@ -621,7 +623,6 @@ def pfb_workload(torch, dev, skip_cpu, n=1 << 26, fs=20e6, steps=10):
     c = chain.Chain(fs, taps=taps, keep_n=keep, decoder=chain.DEC_TS33C, decoder_rate=rate, max_samples=n,
                     max_frames=64, channels=M)
     c.set_stream(torch.cuda.current_stream().cuda_stream)
-    c.set_overlap(OVERLAP)
     x = iq.reshape(1, n, 2)
     rules = (chain.DEC_SOMFY, chain.DEC_BERNER, chain.DEC_MUMBI)
 
@@ -674,6 +675,7 @@ def pfb_workload(torch, dev, skip_cpu, n=1 << 26, fs=20e6, steps=10):
                         "bytes_per_launch": bps * n},
            "verified": "the 3 TS33C frames decode in channel 5, the berner code in channel 40, the mumbi code in "
                        "channel 17, nothing valid anywhere else"}
+    overlapped_pass(torch, c, step, steps, out, n, per=2)
     if not skip_cpu:
         from oracle import dsp as odsp
         m = 1 << 21
@@ -692,7 +694,38 @@ def pfb_workload(torch, dev, skip_cpu, n=1 << 26, fs=20e6, steps=10):
     return out
 
 
-PMC_FILE = "r02_c_pmc.json"   # the committed FETCH_SIZE / WRITE_SIZE passes of the current kernels (tools/profile_round.sh)
+PMC_FILE = "r02_d_pmc.json"   # the committed FETCH_SIZE / WRITE_SIZE passes of the current kernels (tools/profile_round.sh)
+
+
+def progress(msg):
+    """one line per workload on stderr: a long run (under a profiler, say) shows where it is"""
+    print("[bench] " + msg, file=sys.stderr, flush=True)
+
+
+def overlapped_pass(torch, c, step, steps, out, units, per=1, warm=3):
+    """The same steps again with sdr_set_overlap on: ms_per_step / value of `out` become the overlapped ones, the
+    one-stream step and the front-end kernel's time beside a running back end are kept next to them."""
+    if not OVERLAP:
+        return
+    progress("  second pass, overlapped")
+    c.set_overlap(True)
+    for _ in range(warm):
+        step()
+    torch.cuda.synchronize()
+    c.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    front_ms, _back = c.profile_read()
+    c.profile_enable(False)
+    c.set_overlap(False)
+    out["ms_per_step_one_stream"] = out["ms_per_step"]
+    out["value"] = round(units / dt / 1e6, 1)
+    out["ms_per_step"] = round(dt * 1e3, 4)
+    out["streams"] = "sdr_set_overlap: back end of step k beside the front end of step k+1"
+    out["roofline"]["kernel_ms_overlapped"] = round(float(np.mean(front_ms[0::per])), 4)
 
 
 def pmc_traffic(kernel_key, workload_tag):
@@ -826,7 +859,6 @@ def main():
     c = chain.Chain(FS, decim=DECIM, center_freq=F_OFF, taps=taps, decoder=chain.DEC_TS33C, max_batch=ncap,
                     max_frames=max_frames, max_samples=N_PER_CAPTURE)
     c.set_stream(torch.cuda.current_stream().cuda_stream)
-    c.set_overlap(OVERLAP)
     rec = torch.zeros(ncap * max_frames * 96, dtype=torch.uint8, device=dev)
     cnt = torch.zeros(ncap, dtype=torch.int32, device=dev)
     if use_dist:
@@ -842,8 +874,7 @@ def main():
         ev_gathered = [torch.cuda.Event() for _ in range(2)]
     kstep = [0]
 
-    # the stream the exported records are ordered on: the handle's result stream when batches overlap
-    res_stream = torch.cuda.ExternalStream(c.result_stream(), device=dev) if OVERLAP else torch.cuda.current_stream()
+    res_stream = torch.cuda.current_stream()   # the handle's stream: what sdr_export_frames writes is ordered on it
 
     def step():
         c.batch_process(iq)
@@ -943,13 +974,19 @@ def main():
         else:
             line["cpu_baseline"] = None
         if world == 1:
+            progress("ook_batch_cu8")
             other = {"ook_batch_cu8": cu8_workload(torch, dev, iq, pkts, taps)}
             del iq
             torch.cuda.empty_cache()
+            progress("fm_radio_wbfm")
             other["fm_radio_wbfm"] = fm_workload(torch, dev, args.no_cpu_baseline)
+            progress("ook_r_shape_ts33c")
             other["ook_r_shape_ts33c"] = r_shape_workload(torch, dev, args.no_cpu_baseline)
+            progress("wideband_pfb64")
             other["wideband_pfb64"] = pfb_workload(torch, dev, args.no_cpu_baseline)
+            progress("tfa_fsk_discriminator")
             other["tfa_fsk_discriminator"] = tfa_fsk_workload(torch, dev, args.no_cpu_baseline)
+            progress("ook_batch_somfy_berner_mumbi")
             other["ook_batch_somfy_berner_mumbi"] = mixed_emitters_workload(torch, dev, args.no_cpu_baseline)
             line["other_workloads"] = other
         print(json.dumps(line))

@@ -33,7 +33,7 @@ static int chain_restart(sdr_handle* c)
 {
     (void)hipSetDevice(c->device);
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    for (int i = 0; i < 2; ++i) HIPCHK(c, hipMemset(c->d_hist[i], 0, (size_t)c->hist_cap * sizeof(float2)));
+    for (int i = 0; i < 2; ++i) HIPCHK(c, memset_done(c->d_hist[i], 0, (size_t)c->hist_cap * sizeof(float2)));
     reset_stream_counters(c);
     return reset_dec_state(c);
 }
@@ -174,11 +174,11 @@ extern "C" int sdr_fm_create(const sdr_fm_cfg* cfg, sdr_fm** out)
         for (int i = 0; i < 2; ++i) {
             FMCHK(h, dev_alloc((void**)&h->d_chist[i], (size_t)h->chist_len * sizeof(float)));
             FMCHK(h, dev_alloc((void**)&h->d_ehist[i], (size_t)h->ehist_len * sizeof(float)));
-            FMCHK(h, hipMemset(h->d_chist[i], 0, (size_t)h->chist_len * sizeof(float)));
-            FMCHK(h, hipMemset(h->d_ehist[i], 0, (size_t)h->ehist_len * sizeof(float)));
+            FMCHK(h, memset_done(h->d_chist[i], 0, (size_t)h->chist_len * sizeof(float)));
+            FMCHK(h, memset_done(h->d_ehist[i], 0, (size_t)h->ehist_len * sizeof(float)));
         }
         FMCHK(h, dev_alloc((void**)&h->d_deemph, 2 * sizeof(FmDeemphState)));
-        FMCHK(h, hipMemset(h->d_deemph, 0, 2 * sizeof(FmDeemphState)));
+        FMCHK(h, memset_done(h->d_deemph, 0, 2 * sizeof(FmDeemphState)));
         h->stream = h->A->own_stream;
         sdr_set_stream(h->B, (void*)h->stream);
         return SDR_OK;
@@ -228,10 +228,10 @@ extern "C" int sdr_fm_reset(sdr_fm* h)
     rc = chain_restart(h->B);
     if (rc) return fm_fail(h, rc, h->B->err);
     for (int i = 0; i < 2; ++i) {
-        FMCHK(h, hipMemset(h->d_chist[i], 0, (size_t)h->chist_len * sizeof(float)));
-        FMCHK(h, hipMemset(h->d_ehist[i], 0, (size_t)h->ehist_len * sizeof(float)));
+        FMCHK(h, memset_done(h->d_chist[i], 0, (size_t)h->chist_len * sizeof(float)));
+        FMCHK(h, memset_done(h->d_ehist[i], 0, (size_t)h->ehist_len * sizeof(float)));
     }
-    FMCHK(h, hipMemset(h->d_deemph, 0, 2 * sizeof(FmDeemphState)));
+    FMCHK(h, memset_done(h->d_deemph, 0, 2 * sizeof(FmDeemphState)));
     h->c_in = h->c_out = h->e_in = h->e_out = 0;
     h->csel = h->esel = h->dsel = 0;
     h->n1 = h->n2 = h->n4 = 0;

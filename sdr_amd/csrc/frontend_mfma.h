@@ -630,6 +630,10 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))
     };
 
     float2* const dst = reinterpret_cast<float2*>(P.tap + (long long)cap * P.tap_stride);
+    // the NCO table is read by team 0's first commit, in phase 0: every wave's share of it (and of the taps) has
+    // to be in LDS before that.  (Without this barrier a wave that fell behind in the fill left stale entries to
+    // the first tile of its workgroup: about one capture in twenty had a few thousand wrong outputs.)
+    lds_only_barrier();
     if (n_my > 0) issue(tile0 + team);
     const int nphase = ntile + 1;                          // team 0: phases 0 .. 2*n0-1, team 1: 1 .. 2*n1
     for (int p = 0; p < nphase; ++p) {

@@ -32,7 +32,7 @@ static int pfb_upload_taps(sdr_handle* h)
         }
         h->hist_cap = h->hist_len;
     }
-    for (int i = 0; i < 2; ++i) HIPCHK(h, hipMemset(h->d_hist[i], 0, (size_t)h->hist_cap * sizeof(float2)));
+    for (int i = 0; i < 2; ++i) HIPCHK(h, memset_done(h->d_hist[i], 0, (size_t)h->hist_cap * sizeof(float2)));
     reset_stream_counters(h);
     return reset_dec_state(h);
 }
@@ -305,7 +305,7 @@ extern "C" int sdr_redecode_multi(sdr_handle* h, const int32_t* decoders, int n,
         HIPCHK(h, dev_alloc((void**)&h->d_m_cur, (size_t)(need * SDR_CUR_CAP) * sizeof(double)));
         HIPCHK(h, dev_alloc((void**)&h->d_m_st, (size_t)need * sizeof(DecState)));
         HIPCHK(h, dev_alloc((void**)&h->d_m_frames, (size_t)(need * h->cfg.max_frames) * sizeof(sdr_frame)));
-        HIPCHK(h, hipMemset(h->d_m_frames, 0, (size_t)(need * h->cfg.max_frames) * sizeof(sdr_frame)));
+        HIPCHK(h, memset_done(h->d_m_frames, 0, (size_t)(need * h->cfg.max_frames) * sizeof(sdr_frame)));
         h->m_cap = need;
     }
     const double rate = decoder_rate > 0 ? decoder_rate : h->dec_rate;

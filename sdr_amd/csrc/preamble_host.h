@@ -52,7 +52,7 @@ extern "C" int sdr_preamble_create(sdr_preamble** out)
         PCHK(h, hipGetDevice(&h->device));
         PCHK(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
         PCHK(h, hipMalloc((void**)&h->d_st, sizeof(PreambleState)));
-        PCHK(h, hipMemset(h->d_st, 0, sizeof(PreambleState)));
+        PCHK(h, memset_done(h->d_st, 0, sizeof(PreambleState)));
         return SDR_OK;
     };
     int rc = body();

@@ -371,6 +371,16 @@ static hipError_t dev_alloc(void** p, size_t bytes)
     return hipMalloc(p, bytes);
 }
 
+// hipMemset on device memory returns before the fill has run (it is queued on the null stream, which the
+// handles' non-blocking streams do not wait for): a state reset must have landed before the next call queues
+// work on the handle's stream, so wait for it.  (Seen as 1 in 8 wrong audio after sdr_fm_reset: the late fill
+// wiped the history the first chunk had just written.)
+static hipError_t memset_done(void* p, int v, size_t bytes)
+{
+    hipError_t e = hipMemset(p, v, bytes);
+    return e != hipSuccess ? e : hipStreamSynchronize(nullptr);
+}
+
 static int upload_taps(sdr_handle* h)
 {
     const int n = h->ntaps;
@@ -433,7 +443,7 @@ static int upload_taps(sdr_handle* h)
         h->hist_cap = h->hist_len;
     }
     for (int i = 0; i < 2; ++i)
-        HIPCHK(h, hipMemset(h->d_hist[i], 0, (size_t)h->hist_cap * sizeof(float2)));
+        HIPCHK(h, memset_done(h->d_hist[i], 0, (size_t)h->hist_cap * sizeof(float2)));
     return SDR_OK;
 }
 
@@ -530,7 +540,7 @@ static int reset_dec_state(sdr_handle* h)
     const size_t rows = h->pfb_M ? (size_t)h->cfg.max_batch : 1;
     std::vector<DecState> all(rows, s0);
     HIPCHK(h, hipMemcpy(h->d_st, all.data(), rows * sizeof s0, hipMemcpyHostToDevice));
-    HIPCHK(h, hipMemset(h->d_rule, 0, h->rule_rows * sizeof(RuleState)));
+    HIPCHK(h, memset_done(h->d_rule, 0, h->rule_rows * sizeof(RuleState)));
     h->carry_next = h->cfg.thr_init;
     h->carry_last = -1;
     return SDR_OK;
@@ -645,7 +655,7 @@ extern "C" int sdr_create(const sdr_chain_cfg* cfg, sdr_handle** out)
         if (B > 1) pend = 0;
         h->bits_stride = ((nb_max + pend + 63) / 64) * 64;
         HIPCHK(h, dev_alloc((void**)&h->d_bits, (size_t)(B * h->bits_stride)));
-        HIPCHK(h, hipMemset(h->d_bits, 0, (size_t)(B * h->bits_stride)));
+        HIPCHK(h, memset_done(h->d_bits, 0, (size_t)(B * h->bits_stride)));
         if (h->cfg.tap_demod || h->cfg.post_ntaps > 0) {
             h->tap_stride = nout_max * (h->cfg.demod == SDR_DEMOD_NONE ? 2 : 1);
             HIPCHK(h, dev_alloc((void**)&h->d_tap, (size_t)(B * h->tap_stride) * sizeof(float)));
@@ -664,7 +674,7 @@ extern "C" int sdr_create(const sdr_chain_cfg* cfg, sdr_handle** out)
         }
         HIPCHK(h, dev_alloc((void**)&h->d_cur, (size_t)(B * SDR_CUR_CAP) * sizeof(double)));
         HIPCHK(h, dev_alloc((void**)&h->d_st, (size_t)B * sizeof(DecState)));
-        HIPCHK(h, hipMemset(h->d_st, 0, (size_t)B * sizeof(DecState)));
+        HIPCHK(h, memset_done(h->d_st, 0, (size_t)B * sizeof(DecState)));
         h->rule_rows = (B == 64) ? 64 : 1;   // 64: a one-capture channelizer handle may stream (sdr_pfb_create)
         HIPCHK(h, dev_alloc((void**)&h->d_rule, h->rule_rows * sizeof(RuleState)));
         {
@@ -673,7 +683,7 @@ extern "C" int sdr_create(const sdr_chain_cfg* cfg, sdr_handle** out)
         }
         HIPCHK(h, dev_alloc((void**)&h->d_frames, (size_t)(B * h->cfg.max_frames) * sizeof(sdr_frame)));
         // the record has 4 bytes of alignment padding no field assignment reaches: keep them defined
-        HIPCHK(h, hipMemset(h->d_frames, 0, (size_t)(B * h->cfg.max_frames) * sizeof(sdr_frame)));
+        HIPCHK(h, memset_done(h->d_frames, 0, (size_t)(B * h->cfg.max_frames) * sizeof(sdr_frame)));
         h->keep_ctr = h->cfg.keep_n;
         return scratch_init(h);
     };
@@ -725,7 +735,7 @@ extern "C" int sdr_set_post_taps(sdr_handle* h, const float* taps, int n)
     if (!h->d_post_rtaps) HIPCHK(h, dev_alloc((void**)&h->d_post_rtaps, n * sizeof(float)));
     for (int i = 0; i < 2; ++i) {
         if (!h->d_post_hist[i]) HIPCHK(h, dev_alloc((void**)&h->d_post_hist[i], (size_t)(n + 1) * sizeof(float)));
-        HIPCHK(h, hipMemset(h->d_post_hist[i], 0, (size_t)(n + 1) * sizeof(float)));
+        HIPCHK(h, memset_done(h->d_post_hist[i], 0, (size_t)(n + 1) * sizeof(float)));
     }
     HIPCHK(h, hipMemcpy(h->d_post_rtaps, rt.data(), n * sizeof(float), hipMemcpyHostToDevice));
     h->post_taps.assign(taps, taps + n);
@@ -801,8 +811,8 @@ extern "C" int sdr_set_squelch(sdr_handle* h, double threshold_db, double alpha,
         HIPCHK(h, dev_alloc((void**)&h->d_sq_cnt, (size_t)B * sizeof(int32_t)));
         HIPCHK(h, dev_alloc((void**)&h->d_sq_st, (size_t)B * sizeof(SquelchState)));
     }
-    HIPCHK(h, hipMemset(h->d_sq_st, 0, (size_t)B * sizeof(SquelchState)));
-    HIPCHK(h, hipMemset(h->d_sq_cnt, 0, (size_t)B * sizeof(int32_t)));
+    HIPCHK(h, memset_done(h->d_sq_st, 0, (size_t)B * sizeof(SquelchState)));
+    HIPCHK(h, memset_done(h->d_sq_cnt, 0, (size_t)B * sizeof(int32_t)));
     h->sq_alpha = alpha;
     h->sq_thr = std::pow(10.0, threshold_db / 10.0);
     h->sq_gate = gate ? 1 : 0;
@@ -832,13 +842,24 @@ extern "C" int sdr_set_overlap(sdr_handle* h, int on)
     (void)hipSetDevice(h->device);
     OV_JOIN(h);
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    // rocprofv3 counter collection runs one kernel at a time whatever the streams say, and its serialiser was
+    // seen to stall on this two-queue pattern (bench.py under --pmc): keep one stream there, results are the same
+    if (on && getenv("ROCPROF_COUNTER_COLLECTION")) on = 0;
     if (on && !h->bstream) {
         const size_t B = (size_t)h->cfg.max_batch;
-        HIPCHK(h, hipStreamCreateWithFlags(&h->bstream, hipStreamNonBlocking));
+        {
+            // A priority of its own, the highest: the back end is a chain of small latency-bound launches that
+            // should not queue behind the front end's workgroups -- and HIP keeps one pool of hardware queues per
+            // priority, so this stream never lands on the hardware queue of h->stream (two streams of the default
+            // priority can; measured: overlapped steps then ran 10 % slower than on one stream).
+            int least = 0, greatest = 0;
+            HIPCHK(h, hipDeviceGetStreamPriorityRange(&least, &greatest));
+            HIPCHK(h, hipStreamCreateWithPriority(&h->bstream, hipStreamNonBlocking, greatest));
+        }
         HIPCHK(h, hipEventCreateWithFlags(&h->ov_front, hipEventDisableTiming));
         for (int i = 0; i < 2; ++i) HIPCHK(h, hipEventCreateWithFlags(&h->ov_back[i], hipEventDisableTiming));
         HIPCHK(h, dev_alloc((void**)&h->d_bits2, B * (size_t)h->bits_stride));
-        HIPCHK(h, hipMemset(h->d_bits2, 0, B * (size_t)h->bits_stride));
+        HIPCHK(h, memset_done(h->d_bits2, 0, B * (size_t)h->bits_stride));
         HIPCHK(h, dev_alloc((void**)&h->d_tsum2, B * (size_t)h->tsum_stride * sizeof(TileSum)));
     }
     h->overlap = on != 0;

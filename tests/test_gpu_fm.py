@@ -76,3 +76,29 @@ def test_fm_audio_fir_vector_form(monkeypatch):
         r.process(iq[123457:])
         got = np.concatenate([a, r.fetch(2)])
     _cmp(got, want[2], exact=True)
+
+
+def test_fm_chain_repeats_bit_for_bit():
+    """The same two ragged chunks again and again, a large call in between to disturb the caches: every stage must
+    repeat bit for bit.  (k_frontend_mfma2 once read its LDS copy of the rotator table before every wave had
+    written its share: about one run in twenty had a few thousand wrong samples in stage 0.)"""
+    torch = pytest.importorskip("torch")
+    fs, m = 2.4e6, 1 << 21
+    iq = synth.fm_iq(m, fs, f_off=200e3, seed=7)
+    big = torch.from_numpy(iq.view(np.float32)).to("cuda:0").repeat(8, 1)
+    half = m // 2 + 4321
+    with fm.FmRadio(samp_rate=fs, shift=200e3, max_samples=8 * m) as r:
+        ref = None
+        for it in range(40):
+            r.process(big)
+            r.reset()
+            outs = []
+            for chunk in (iq[:half], iq[half:]):
+                r.process(chunk)
+                outs.append([r.fetch(s).copy() for s in range(5)])
+            if ref is None:
+                ref = outs
+                continue
+            for c in range(2):
+                for s in range(5):
+                    assert np.array_equal(ref[c][s].view(np.uint32), outs[c][s].view(np.uint32)), (it, c, s)
