@@ -59,7 +59,7 @@ def test_one_very_long_capture_in_one_call_and_streamed():
 
 
 def test_every_chain_shape_repeats_bit_for_bit():
-    """tools/stress_repeat.py: nine chain shapes (every front-end kernel, the channelizer, long and short rows) over
+    """tools/stress_repeat.py: fourteen chain shapes (every front-end kernel, two-stage and squelch chains, the channelizer, long and short rows) over
     the same input 12 times each with a large unrelated batch in between; sliced bytes, demodulated floats and frames
     must not change from run to run (60 repeats each by hand: 0 differing).  A barrier missing in one kernel showed
     as one wrong run in twenty, not as a parity failure."""

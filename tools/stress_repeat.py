@@ -34,6 +34,15 @@ def run(reps, verbose=True):
         ("xlating D=1 121 taps", dict(fs=1e6, decim=1, center_freq=100e3, taps=lp(1e6, 20e3, 40e3), keep_n=50, decoder=chain.DEC_TS33C, decoder_rate=2e4), noise(8, 1 << 19)),
         ("D=4 131 taps, no demod (two-team kernel)", dict(fs=2.4e6, decim=4, taps=lp(2.4e6, 250e3, 100e3), demod=chain.DEMOD_NONE, tap_demod=True), noise(2, 1 << 21)),
         ("D=2 mfma quad", dict(fs=1e6, decim=2, taps=lp(1e6, 100e3, 50e3), demod=chain.DEMOD_QUAD, demod_gain=1.0, thr=(-0.2, 0.2), tap_demod=True), noise(8, 1 << 19)),
+        ("post-demod filter (TFA analyzer2 wiring)", dict(fs=2e6, decim=1, center_freq=500e3, demod=chain.DEMOD_MAG2, thr=(0.2, 0.4), keep_n=1,
+                                                      post_taps=chain.low_pass(1.0, 2e6, 100e3, 300e3), tap_demod=True, decoder=chain.DEC_TFA_GRC), noise(4, 1 << 19)),
+        ("prefilter + resampler 1/10 (mumbi FS300 wiring)", dict(fs=2e6, pre_taps=lp(2e6, 100e3, 50e3), pre_decim=1, decim=10, taps=lp(2e6, 80e3, 40e3), thr=(0.1, 0.4),
+                                                             decoder=chain.DEC_MUMBI), noise(4, 1 << 19)),
+        ("gating squelch + discriminator", dict(fs=2e6, decim=1, taps=chain.low_pass(1, 2e6, 500e3, 250e3, chain.WIN_BLACKMAN), demod=chain.DEMOD_QUAD, demod_gain=3.0,
+                                            thr=(-0.2, 0.2), squelch=(-12.0, 1e-3), decoder=chain.DEC_TFA_GRC), noise(4, 1 << 19)),
+        ("cu8 D=1 121 translated taps", dict(fs=1e6, decim=1, center_freq=100e3, taps=lp(1e6, 20e3, 40e3), keep_n=50, decoder=chain.DEC_TS33C, decoder_rate=2e4,
+                                         input_format="cu8"), cu8(8, 1 << 18)),
+        ("cu8 D=10", dict(fs=1e6, decim=10, taps=lp(1e6, 20e3, 40e3), decoder=chain.DEC_BERNER, input_format="cu8"), cu8(64, 1 << 18)),
         ("pfb64", dict(fs=20e6, taps=chain.low_pass(1.0, 20e6, 100e3, 100e3), keep_n=16, decoder=chain.DEC_TS33C, decoder_rate=20e6 / 64 / 16, channels=64), noise(1, 1 << 23)),
     ]
     big = noise(64, 1 << 18)
