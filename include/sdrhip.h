@@ -121,6 +121,8 @@ typedef struct sdr_frame {
                             lim[0] = frame start (symbol index), lim[1] = message length */
     int32_t temp_tenths; /* TS33C/TFA/kwmobile/baldr temperature in 0.1 C */
     int32_t pad_;
+    int32_t pad2_;     /* always 0.  Spelled out (the compiler would put 4 bytes of padding here anyway) so that it is
+                          assigned like any field: records then compare equal byte for byte */
     double lim[2];     /* TS33C: pulse/gap short limit (us) | TFA: symbol_length (us), 0 */
     int64_t end_pos;   /* index (decoder-rate samples, per call) where the frame ended */
 } sdr_frame;

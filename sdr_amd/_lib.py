@@ -79,6 +79,7 @@ class Frame(C.Structure):
         ("v", C.c_int32 * 4),
         ("temp_tenths", C.c_int32),
         ("pad_", C.c_int32),
+        ("pad2_", C.c_int32),
         ("lim", C.c_double * 2),
         ("end_pos", C.c_int64),
     ]

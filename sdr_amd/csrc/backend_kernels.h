@@ -99,17 +99,12 @@ SDR_HD inline double np_pairwise_sum_small(const double* a, int n)
 
 SDR_HD inline void frame_init(sdr_frame* f, int cap, int dec, long long end_pos)
 {
+    // every byte of the record, pad2_ and all, then the three fields that are not zero: field-by-field
+    // assignment let the compiler merge neighbouring stores across the hole in front of `lim` and fill it with
+    // whatever the register held (seen as records that differed in two bytes under a HIP-graph replay)
+    __builtin_memset(f, 0, sizeof *f);
     f->capture = cap;
     f->decoder = dec;
-    f->status = 0;
-    f->nbits = 0;
-    f->nbytes = 0;
-    for (int i = 0; i < 16; ++i) f->bytes[i] = 0;
-    for (int i = 0; i < 8; ++i) f->raw[i] = 0;
-    for (int i = 0; i < 4; ++i) f->v[i] = 0;
-    f->temp_tenths = 0;
-    f->pad_ = 0;
-    f->lim[0] = f->lim[1] = 0.0;
     f->end_pos = end_pos;
 }
 

@@ -73,3 +73,40 @@ def test_static_entry_point_matches_batch_process_twice():
             with pytest.raises(_lib.SdrError) as ei:
                 wide.batch_process_static(big, bits, rec, cnt)
             assert ei.value.code == _lib.SDR_E_CAPACITY and "static array" in str(ei.value)
+
+
+def test_static_entry_point_under_graph_capture():
+    """One of the callers the entry point exists for: captured into a HIP graph (torch.cuda.graph), nothing runs at
+    capture time; every replay gives the bytes, records and counts sdr_batch_process gives for the input tensor's
+    contents at that moment."""
+    fs, D, max_frames = 1e6, 50, 4
+    taps = chain.low_pass(1.0, fs, 20e3, 40e3)
+    dev = torch.device("cuda", 0)
+    ncap, n = 24, 1 << 18
+    kw = dict(decim=D, center_freq=100e3, taps=taps, decoder=chain.DEC_TS33C, max_batch=32, max_frames=max_frames, max_samples=n)
+    with chain.Chain(fs, **kw) as ref, chain.Chain(fs, **kw) as c:
+        batches = [torch.from_numpy(_batch(ncap, n, fs, seed).view(np.float32).reshape(ncap, n, 2)).to(dev) for seed in (31, 32)]
+        x = batches[0].clone()
+        nb = n // D
+        bits = torch.zeros(ncap * nb, dtype=torch.uint8, device=dev)
+        rec = torch.zeros(ncap * max_frames * C.sizeof(_lib.Frame), dtype=torch.uint8, device=dev)
+        cnt = torch.zeros(ncap, dtype=torch.int32, device=dev)
+        st = torch.cuda.Stream(device=dev)
+        c.set_stream(st.cuda_stream)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=st):
+            c.batch_process_static(x, bits, rec, cnt)
+        torch.cuda.synchronize()
+        assert int(cnt.sum()) == 0 and int(bits.sum()) == 0          # captured, not run
+        for b in batches + batches[:1]:
+            x.copy_(b)
+            torch.cuda.synchronize()
+            g.replay()
+            torch.cuda.synchronize()
+            want_nb, want_bits, want_rec, want_cnt = _reference(ref, b, max_frames)
+            assert want_nb == nb and want_cnt.sum() >= ncap
+            assert np.array_equal(cnt.cpu().numpy(), want_cnt)
+            assert np.array_equal(bits.cpu().numpy(), want_bits)
+            assert np.array_equal(rec.cpu().numpy(), want_rec)
+        del g
