@@ -365,10 +365,16 @@ static unsigned long long host_nco_inc(double fc, double fs, int D)
 }
 
 // ------------------------------------------------------------------ helpers
+// SDR_POISON=1 (test switch): every device buffer starts as 0xA5 bytes instead of whatever hipMalloc hands out
+// (zeros, in a fresh process), so that a kernel reading memory nothing has written shows up in the test suite
 static hipError_t dev_alloc(void** p, size_t bytes)
 {
+    static const bool poison = getenv("SDR_POISON") != nullptr;
     if (bytes == 0) bytes = 16;
-    return hipMalloc(p, bytes);
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess || !poison) return e;
+    e = hipMemset(*p, 0xA5, bytes);
+    return e != hipSuccess ? e : hipStreamSynchronize(nullptr);
 }
 
 // hipMemset on device memory returns before the fill has run (it is queued on the null stream, which the
