@@ -62,7 +62,7 @@ extern "C" int sdr_fm_destroy(sdr_fm* h)
     void* ptrs[] = {h->d_ataps, h->d_rtaps, h->d_a2, h->d_a3, h->d_audio, h->d_chist[0], h->d_chist[1], h->d_ehist[0],
                     h->d_ehist[1], h->d_deemph};
     for (void* p : ptrs)
-        if (p) (void)hipFree(p);
+        if (p) (void)dev_free(p);
     delete h;
     return SDR_OK;
 }

@@ -17,7 +17,7 @@ static int pfb_upload_taps(sdr_handle* h)
     if (!P) return fail(h, SDR_E_ARG, "channelizer: at most 16 taps per branch (1024 taps)");
     std::vector<float> t((size_t)P * M, 0.0f);
     for (int k = 0; k < n; ++k) t[k] = h->proto_taps[k];
-    if (h->d_pfb_taps) (void)hipFree(h->d_pfb_taps);
+    if (h->d_pfb_taps) (void)dev_free(h->d_pfb_taps);
     h->d_pfb_taps = nullptr;
     HIPCHK(h, dev_alloc((void**)&h->d_pfb_taps, t.size() * sizeof(float)));
     HIPCHK(h, hipMemcpy(h->d_pfb_taps, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -26,7 +26,7 @@ static int pfb_upload_taps(sdr_handle* h)
     h->hist_len = P * M - 1 + 2 * M;
     if (h->hist_len > h->hist_cap) {
         for (int i = 0; i < 2; ++i) {
-            if (h->d_hist[i]) (void)hipFree(h->d_hist[i]);
+            if (h->d_hist[i]) (void)dev_free(h->d_hist[i]);
             h->d_hist[i] = nullptr;
             HIPCHK(h, dev_alloc((void**)&h->d_hist[i], (size_t)h->hist_len * sizeof(float2)));
         }
@@ -297,7 +297,7 @@ extern "C" int sdr_redecode_multi(sdr_handle* h, const int32_t* decoders, int n,
         OV_JOIN(h);
         HIPCHK(h, hipStreamSynchronize(h->stream));
         for (void* p : {(void*)h->d_m_cur, (void*)h->d_m_st, (void*)h->d_m_frames})
-            if (p) (void)hipFree(p);
+            if (p) (void)dev_free(p);
         h->d_m_cur = nullptr;
         h->d_m_st = nullptr;
         h->d_m_frames = nullptr;

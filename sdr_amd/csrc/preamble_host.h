@@ -32,9 +32,9 @@ extern "C" int sdr_preamble_destroy(sdr_preamble* h)
     if (!h) return SDR_OK;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    if (h->d_in) (void)hipFree(h->d_in);
-    if (h->d_out) (void)hipFree(h->d_out);
-    if (h->d_st) (void)hipFree(h->d_st);
+    if (h->d_in) (void)dev_free(h->d_in);
+    if (h->d_out) (void)dev_free(h->d_out);
+    if (h->d_st) (void)dev_free(h->d_st);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return SDR_OK;
@@ -51,7 +51,7 @@ extern "C" int sdr_preamble_create(sdr_preamble** out)
     auto body = [&]() -> int {
         PCHK(h, hipGetDevice(&h->device));
         PCHK(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-        PCHK(h, hipMalloc((void**)&h->d_st, sizeof(PreambleState)));
+        PCHK(h, dev_alloc((void**)&h->d_st, sizeof(PreambleState)));
         PCHK(h, memset_done(h->d_st, 0, sizeof(PreambleState)));
         return SDR_OK;
     };
@@ -74,13 +74,13 @@ extern "C" int sdr_preamble_work(sdr_preamble* h, const int8_t* in, size_t n, in
     int8_t* y = outp;
     if (!is_dev) {
         if (n > h->cap) {
-            if (h->d_in) (void)hipFree(h->d_in);
-            if (h->d_out) (void)hipFree(h->d_out);
+            if (h->d_in) (void)dev_free(h->d_in);
+            if (h->d_out) (void)dev_free(h->d_out);
             h->d_in = h->d_out = nullptr;
             h->cap = 0;
             const size_t want = n < 65536 ? 65536 : n;
-            PCHK(h, hipMalloc((void**)&h->d_in, want));
-            PCHK(h, hipMalloc((void**)&h->d_out, want));
+            PCHK(h, dev_alloc((void**)&h->d_in, want));
+            PCHK(h, dev_alloc((void**)&h->d_out, want));
             h->cap = want;
         }
         if (n) PCHK(h, hipMemcpyAsync(h->d_in, in, n, hipMemcpyHostToDevice, h->stream));

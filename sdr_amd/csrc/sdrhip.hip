@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <unordered_map>
 #include <string>
 #include <vector>
 
@@ -366,15 +367,58 @@ static unsigned long long host_nco_inc(double fc, double fs, int D)
 
 // ------------------------------------------------------------------ helpers
 // SDR_POISON=1 (test switch): every device buffer starts as 0xA5 bytes instead of whatever hipMalloc hands out
-// (zeros, in a fresh process), so that a kernel reading memory nothing has written shows up in the test suite
+// (zeros, in a fresh process), so that a kernel reading memory nothing has written shows up in the test suite;
+// and every buffer gets a 512-byte guard band behind it that must still be 0xA5 when the buffer is freed
+// (sdr_selftest_guard_hits() counts the bands that were not: writes past a buffer's end).
+#define SDR_GUARD_BYTES 512
+static std::mutex g_guard_mu;
+static std::unordered_map<void*, size_t> g_guard_size;
+static int g_guard_hits = 0, g_guard_checked = 0;
+static bool poison_on()
+{
+    static const bool on = getenv("SDR_POISON") != nullptr;
+    return on;
+}
 static hipError_t dev_alloc(void** p, size_t bytes)
 {
-    static const bool poison = getenv("SDR_POISON") != nullptr;
     if (bytes == 0) bytes = 16;
-    hipError_t e = hipMalloc(p, bytes);
-    if (e != hipSuccess || !poison) return e;
-    e = hipMemset(*p, 0xA5, bytes);
-    return e != hipSuccess ? e : hipStreamSynchronize(nullptr);
+    if (!poison_on()) return hipMalloc(p, bytes);
+    hipError_t e = hipMalloc(p, bytes + SDR_GUARD_BYTES);
+    if (e != hipSuccess) return e;
+    e = hipMemset(*p, 0xA5, bytes + SDR_GUARD_BYTES);
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+    std::lock_guard<std::mutex> lk(g_guard_mu);
+    g_guard_size[*p] = bytes;
+    return e;
+}
+static hipError_t dev_free(void* p)
+{
+    if (p && poison_on()) {
+        size_t bytes = 0;
+        {
+            std::lock_guard<std::mutex> lk(g_guard_mu);
+            auto it = g_guard_size.find(p);
+            if (it != g_guard_size.end()) {
+                bytes = it->second;
+                g_guard_size.erase(it);
+            }
+        }
+        if (bytes) {
+            unsigned char g[SDR_GUARD_BYTES];
+            (void)hipDeviceSynchronize();
+            if (hipMemcpy(g, static_cast<unsigned char*>(p) + bytes, sizeof g, hipMemcpyDeviceToHost) == hipSuccess) {
+                int bad = 0;
+                for (unsigned char b : g) bad += b != 0xA5;
+                std::lock_guard<std::mutex> lk(g_guard_mu);
+                g_guard_checked++;
+                if (bad) {
+                    g_guard_hits++;
+                    fprintf(stderr, "sdrhip: %d guard bytes behind a %zu-byte device buffer were overwritten\n", bad, bytes);
+                }
+            }
+        }
+    }
+    return hipFree(p);
 }
 
 // hipMemset on device memory returns before the fill has run (it is queued on the null stream, which the
@@ -432,7 +476,7 @@ static int upload_taps(sdr_handle* h)
         }
         h->ktaps_n = n;
     }
-    if (h->d_rtaps) (void)hipFree(h->d_rtaps);
+    if (h->d_rtaps) (void)dev_free(h->d_rtaps);
     h->d_rtaps = nullptr;
     HIPCHK(h, dev_alloc((void**)&h->d_rtaps, rt.size() * sizeof(float)));
     HIPCHK(h, hipMemcpy(h->d_rtaps, rt.data(), rt.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -442,7 +486,7 @@ static int upload_taps(sdr_handle* h)
     h->hist_len = n - 1 + 2 * h->cfg.decim;
     if (h->hist_len > h->hist_cap) {
         for (int i = 0; i < 2; ++i) {
-            if (h->d_hist[i]) (void)hipFree(h->d_hist[i]);
+            if (h->d_hist[i]) (void)dev_free(h->d_hist[i]);
             h->d_hist[i] = nullptr;
             HIPCHK(h, dev_alloc((void**)&h->d_hist[i], (size_t)h->hist_len * sizeof(float2)));
         }
@@ -576,7 +620,7 @@ extern "C" int sdr_destroy(sdr_handle* h)
                     h->d_cur, h->d_st, h->d_rule, h->d_frames, h->d_m_cur, h->d_m_st, h->d_m_frames, h->d_sq_y, h->d_sq_z, h->d_sq_cnt, h->d_sq_st,
                     h->d_post_hist[0], h->d_post_hist[1], h->d_pack, h->d_pfb_taps, h->d_pfb_tw};
     for (void* p : ptrs)
-        if (p) (void)hipFree(p);
+        if (p) (void)dev_free(p);
     for (hipEvent_t e : h->pev) (void)hipEventDestroy(e);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -902,7 +946,7 @@ extern "C" int sdr_timer_elapsed_ms(sdr_handle* h, float* ms)
 static int ensure_iq_staging(sdr_handle* h, size_t samples)
 {
     if (samples <= h->iq_cap) return SDR_OK;
-    if (h->d_iq) (void)hipFree(h->d_iq);
+    if (h->d_iq) (void)dev_free(h->d_iq);
     h->d_iq = nullptr;
     h->iq_cap = 0;
     HIPCHK(h, dev_alloc((void**)&h->d_iq, samples * sizeof(float2)));
@@ -1553,7 +1597,7 @@ static int rows_to_host(sdr_handle* h, void* dst, const void* src, size_t spitch
     }
     const size_t total = width * rows;
     if (total > h->pack_cap) {
-        if (h->d_pack) (void)hipFree(h->d_pack);
+        if (h->d_pack) (void)dev_free(h->d_pack);
         h->d_pack = nullptr;
         h->pack_cap = 0;
         HIPCHK(h, dev_alloc((void**)&h->d_pack, total));

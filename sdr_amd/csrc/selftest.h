@@ -111,3 +111,11 @@ extern "C" SDR_API int sdr_selftest_dec_work(void* p, const int8_t* bits, size_t
     }
     return d->st.overflow ? SDR_E_OVERFLOW : SDR_OK;
 }
+
+// SDR_POISON runs: guard bands found overwritten when their buffers were freed / bands checked so far
+extern "C" SDR_API int sdr_selftest_guard_hits(int* checked)
+{
+    std::lock_guard<std::mutex> lk(g_guard_mu);
+    if (checked) *checked = g_guard_checked;
+    return g_guard_hits;
+}

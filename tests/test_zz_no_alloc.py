@@ -110,3 +110,19 @@ def test_static_entry_point_under_graph_capture():
             assert np.array_equal(bits.cpu().numpy(), want_bits)
             assert np.array_equal(rec.cpu().numpy(), want_rec)
         del g
+
+
+def test_zz_guard_bands_behind_device_buffers():
+    """Collected last.  Under SDR_POISON=1 every device buffer the library allocated had a 512-byte guard band
+    behind it, checked when the buffer was freed: none may have been written.  (Without the switch: nothing to
+    check, the counter stays 0.)"""
+    import gc
+    import os
+    gc.collect()                      # handles of earlier tests are freed by now
+    L = _lib.load()
+    L.sdr_selftest_guard_hits.restype = C.c_int
+    L.sdr_selftest_guard_hits.argtypes = [C.POINTER(C.c_int)]
+    checked = C.c_int(0)
+    assert L.sdr_selftest_guard_hits(C.byref(checked)) == 0
+    if os.environ.get("SDR_POISON"):
+        assert checked.value > 100
