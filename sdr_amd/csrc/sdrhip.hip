@@ -368,8 +368,8 @@ static unsigned long long host_nco_inc(double fc, double fs, int D)
 // ------------------------------------------------------------------ helpers
 // SDR_POISON=1 (test switch): every device buffer starts as 0xA5 bytes instead of whatever hipMalloc hands out
 // (zeros, in a fresh process), so that a kernel reading memory nothing has written shows up in the test suite;
-// and every buffer gets a 512-byte guard band behind it that must still be 0xA5 when the buffer is freed
-// (sdr_selftest_guard_hits() counts the bands that were not: writes past a buffer's end).
+// and every buffer gets a 512-byte guard band in front of it and one behind it that must still be 0xA5 when the
+// buffer is freed (sdr_selftest_guard_hits() counts the buffers whose bands were not: writes outside a buffer).
 #define SDR_GUARD_BYTES 512
 static std::mutex g_guard_mu;
 static std::unordered_map<void*, size_t> g_guard_size;
@@ -383,42 +383,45 @@ static hipError_t dev_alloc(void** p, size_t bytes)
 {
     if (bytes == 0) bytes = 16;
     if (!poison_on()) return hipMalloc(p, bytes);
-    hipError_t e = hipMalloc(p, bytes + SDR_GUARD_BYTES);
+    void* base = nullptr;
+    hipError_t e = hipMalloc(&base, bytes + 2 * SDR_GUARD_BYTES);
     if (e != hipSuccess) return e;
-    e = hipMemset(*p, 0xA5, bytes + SDR_GUARD_BYTES);
+    e = hipMemset(base, 0xA5, bytes + 2 * SDR_GUARD_BYTES);
     if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+    *p = static_cast<unsigned char*>(base) + SDR_GUARD_BYTES;   // a band in front (512 keeps hipMalloc's alignment) and one behind
     std::lock_guard<std::mutex> lk(g_guard_mu);
     g_guard_size[*p] = bytes;
     return e;
 }
 static hipError_t dev_free(void* p)
 {
-    if (p && poison_on()) {
-        size_t bytes = 0;
-        {
-            std::lock_guard<std::mutex> lk(g_guard_mu);
-            auto it = g_guard_size.find(p);
-            if (it != g_guard_size.end()) {
-                bytes = it->second;
-                g_guard_size.erase(it);
-            }
-        }
-        if (bytes) {
-            unsigned char g[SDR_GUARD_BYTES];
-            (void)hipDeviceSynchronize();
-            if (hipMemcpy(g, static_cast<unsigned char*>(p) + bytes, sizeof g, hipMemcpyDeviceToHost) == hipSuccess) {
-                int bad = 0;
-                for (unsigned char b : g) bad += b != 0xA5;
-                std::lock_guard<std::mutex> lk(g_guard_mu);
-                g_guard_checked++;
-                if (bad) {
-                    g_guard_hits++;
-                    fprintf(stderr, "sdrhip: %d guard bytes behind a %zu-byte device buffer were overwritten\n", bad, bytes);
-                }
-            }
+    if (!p || !poison_on()) return hipFree(p);
+    size_t bytes = 0;
+    {
+        std::lock_guard<std::mutex> lk(g_guard_mu);
+        auto it = g_guard_size.find(p);
+        if (it != g_guard_size.end()) {
+            bytes = it->second;
+            g_guard_size.erase(it);
         }
     }
-    return hipFree(p);
+    if (!bytes) return hipFree(p);   // not from dev_alloc
+    unsigned char* const base = static_cast<unsigned char*>(p) - SDR_GUARD_BYTES;
+    unsigned char g[2][SDR_GUARD_BYTES];
+    (void)hipDeviceSynchronize();
+    if (hipMemcpy(g[0], base, SDR_GUARD_BYTES, hipMemcpyDeviceToHost) == hipSuccess &&
+        hipMemcpy(g[1], static_cast<unsigned char*>(p) + bytes, SDR_GUARD_BYTES, hipMemcpyDeviceToHost) == hipSuccess) {
+        int bad[2] = {0, 0};
+        for (int k = 0; k < 2; ++k)
+            for (unsigned char b : g[k]) bad[k] += b != 0xA5;
+        std::lock_guard<std::mutex> lk(g_guard_mu);
+        g_guard_checked++;
+        if (bad[0] || bad[1]) {
+            g_guard_hits++;
+            fprintf(stderr, "sdrhip: guard bytes around a %zu-byte device buffer were overwritten (%d in front, %d behind)\n", bytes, bad[0], bad[1]);
+        }
+    }
+    return hipFree(base);
 }
 
 // hipMemset on device memory returns before the fill has run (it is queued on the null stream, which the
