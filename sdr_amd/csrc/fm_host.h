@@ -25,6 +25,7 @@ struct sdr_fm {
     unsigned long long c_in = 0, c_out = 0;   // discriminator floats consumed / audio-FIR outputs emitted
     unsigned long long e_in = 0, e_out = 0;   // de-emphasised floats consumed / audio samples emitted
     FmDeemphState* d_deemph = nullptr;        // two slots, read dsel / write dsel^1
+    TailBatch tails{};                        // the call's four history updates, flushed in one launch at its end
 };
 
 // last H floats of (hist ++ x[0..n)) -> the other history buffer
@@ -208,12 +209,7 @@ static int fm_hist_update(sdr_fm* h, float** bufs, int& sel, int H, const float*
     if (n <= 0 || H <= 0) return SDR_OK;
     float* cur = bufs[sel];
     float* nxt = bufs[sel ^ 1];
-    if (n >= H)
-        FMCHK(h, hipMemcpyAsync(nxt, x + (n - H), (size_t)H * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
-    else {
-        FMCHK(h, hipMemcpyAsync(nxt, cur + n, (size_t)(H - n) * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
-        FMCHK(h, hipMemcpyAsync(nxt + (H - n), x, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
-    }
+    FMCHK(h, tail_update(h->stream, cur, x, (size_t)H * sizeof(float), (size_t)n * sizeof(float), nxt, &h->tails));
     sel ^= 1;
     return SDR_OK;
 }
@@ -243,10 +239,24 @@ extern "C" int sdr_fm_reset(sdr_fm* h)
 // sample), the audio FIR's history and decimation phase, the de-emphasis delay line (exact, double), the
 // audio resampler's history and output phase.  The first call after create / sdr_fm_reset is the capture from
 // stream start; any chunking of a stream yields the same audio.
+static int fm_process_body(sdr_fm* h, const void* iq, size_t n, int is_dev, size_t* n_audio);
 extern "C" int sdr_fm_process(sdr_fm* h, const void* iq, size_t n, int is_dev, size_t* n_audio)
 {
     if (!h || (!iq && n)) return fm_fail(h, SDR_E_ARG, "sdr_fm_process: bad argument");
     if (n > h->cfg.max_samples) return fm_fail(h, SDR_E_CAPACITY, "sdr_fm_process: chunk larger than max_samples");
+    // the blocks' memories (two channel-filter histories, audio FIR, audio resampler) are updated by ONE launch
+    // behind the call's last kernel; whatever path the body leaves by, what it collected is flushed
+    h->tails.count = 0;
+    h->A->tail_defer = h->B->tail_defer = &h->tails;
+    int rc = fm_process_body(h, iq, n, is_dev, n_audio);
+    h->A->tail_defer = h->B->tail_defer = nullptr;
+    hipError_t e = tail_flush(h->stream, &h->tails);
+    if (rc == SDR_OK && e != hipSuccess) return fm_fail(h, SDR_E_HIP, std::string("history update: ") + hipGetErrorString(e));
+    return rc;
+}
+
+static int fm_process_body(sdr_fm* h, const void* iq, size_t n, int is_dev, size_t* n_audio)
+{
     h->n1 = h->n2 = h->n4 = 0;
     if (n_audio) *n_audio = 0;
     int rc = sdr_process_iq(h->A, iq, n, is_dev, nullptr);

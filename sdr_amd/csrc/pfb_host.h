@@ -226,12 +226,7 @@ static int pfb_stream(sdr_handle* h, const void* iq, size_t n, int is_dev, sdr_o
         const char* xb = reinterpret_cast<const char*>(x);
         char* cur = reinterpret_cast<char*>(h->d_hist[h->hist_sel]);
         char* nxt = reinterpret_cast<char*>(h->d_hist[h->hist_sel ^ 1]);
-        if (n >= H)
-            HIPCHK(h, hipMemcpyAsync(nxt, xb + (n - H) * ss, H * ss, hipMemcpyDeviceToDevice, h->stream));
-        else {
-            HIPCHK(h, hipMemcpyAsync(nxt, cur + n * ss, (H - n) * ss, hipMemcpyDeviceToDevice, h->stream));
-            HIPCHK(h, hipMemcpyAsync(nxt + (H - n) * ss, xb, n * ss, hipMemcpyDeviceToDevice, h->stream));
-        }
+        HIPCHK(h, tail_update(h->stream, cur, xb, H * ss, n * ss, nxt));
         h->hist_sel ^= 1;
     }
     h->in_count = A + n;

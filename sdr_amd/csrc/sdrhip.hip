@@ -118,6 +118,7 @@ struct sdr_handle {
     long long seg_min_row = SDR_SEG_MIN_ROW;   // rows this long take the segment- and piece-parallel back end (env SDR_SEG_MIN)
 
     // internal modes used by the FM chain (fm_host.h)
+    struct TailBatch* tail_defer = nullptr;   // set by the FM object around its calls: history updates are collected, not launched
     bool prerotate = false;   // center_freq applies to the INPUT samples (xlating taps=[1] then FIR)
     bool skip_slice = false;  // demod floats only: no slicer, no back end
 
@@ -945,6 +946,67 @@ extern "C" int sdr_timer_elapsed_ms(sdr_handle* h, float* ms)
     return SDR_OK;
 }
 
+// ------------------------------------------------------------------ streaming history
+// nxt[i] = (cur ++ x)[n + i], i in [0, H): what a block remembers for its next call -- the last H units of its
+// history followed by the n new ones -- in one small launch on the call's stream (it was one or two
+// hipMemcpyAsync device-to-device copies per memory: each a command of its own with a copy engine's hand-over
+// around it; the FM chain updates four memories per call).  Units of 2 bytes: cu8 samples, floats, complex64.
+__global__ void k_tail_update(const unsigned short* __restrict__ cur, const unsigned short* __restrict__ x, long long H,
+                              long long n, unsigned short* __restrict__ nxt)
+{
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < H; i += (long long)gridDim.x * blockDim.x) {
+        const long long j = i + n;
+        nxt[i] = j < H ? cur[j] : x[j - H];
+    }
+}
+// Several memories in one launch (blockIdx.y picks one): a flowgraph object that runs several blocks per call
+// (sdr_fm_process) collects its blocks' updates here and flushes them once, at the end of the call -- every
+// source stays intact until then.
+struct TailJob {
+    const unsigned short *cur, *x;
+    long long H, n;
+    unsigned short* nxt;
+};
+struct TailBatch {
+    TailJob job[6];
+    int count;
+};
+__global__ void k_tail_update_batch(TailBatch B)
+{
+    const TailJob J = B.job[blockIdx.y];
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < J.H; i += (long long)gridDim.x * blockDim.x) {
+        const long long j = i + J.n;
+        J.nxt[i] = j < J.H ? J.cur[j] : J.x[j - J.H];
+    }
+}
+static hipError_t tail_flush(hipStream_t stream, TailBatch* tb)
+{
+    if (!tb || tb->count == 0) return hipSuccess;
+    long long hmax = 0;
+    for (int i = 0; i < tb->count; ++i) hmax = tb->job[i].H > hmax ? tb->job[i].H : hmax;
+    long long blocks = (hmax + 255) / 256;
+    if (blocks > 256) blocks = 256;
+    hipLaunchKernelGGL(k_tail_update_batch, dim3((unsigned)blocks, (unsigned)tb->count), dim3(256), 0, stream, *tb);
+    tb->count = 0;
+    return hipGetLastError();
+}
+static hipError_t tail_update(hipStream_t stream, const void* cur, const void* x, size_t h_bytes, size_t n_bytes, void* nxt,
+                              TailBatch* defer = nullptr)
+{
+    if (h_bytes == 0 || n_bytes == 0) return hipSuccess;
+    if (defer && defer->count < 6) {
+        defer->job[defer->count++] = TailJob{(const unsigned short*)cur, (const unsigned short*)x, (long long)(h_bytes / 2),
+                                             (long long)(n_bytes / 2), (unsigned short*)nxt};
+        return hipSuccess;
+    }
+    const long long H = (long long)(h_bytes / 2), n = (long long)(n_bytes / 2);
+    long long blocks = (H + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(k_tail_update, dim3((unsigned)blocks), dim3(256), 0, stream, (const unsigned short*)cur,
+                       (const unsigned short*)x, H, n, (unsigned short*)nxt);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------ launches
 static int ensure_iq_staging(sdr_handle* h, size_t samples)
 {
@@ -1514,12 +1576,7 @@ extern "C" int sdr_process_iq(sdr_handle* h, const void* iq, size_t n, int is_de
         const char* xb = reinterpret_cast<const char*>(x);
         char* cur = reinterpret_cast<char*>(h->d_hist[h->hist_sel]);
         char* nxt = reinterpret_cast<char*>(h->d_hist[h->hist_sel ^ 1]);
-        if (n >= H)
-            HIPCHK(h, hipMemcpyAsync(nxt, xb + (n - H) * ss, H * ss, hipMemcpyDeviceToDevice, h->stream));
-        else {
-            HIPCHK(h, hipMemcpyAsync(nxt, cur + n * ss, (H - n) * ss, hipMemcpyDeviceToDevice, h->stream));
-            HIPCHK(h, hipMemcpyAsync(nxt + (H - n) * ss, xb, n * ss, hipMemcpyDeviceToDevice, h->stream));
-        }
+        HIPCHK(h, tail_update(h->stream, cur, xb, H * ss, n * ss, nxt, h->tail_defer));
         h->hist_sel ^= 1;
     }
     // history of the post-demod filter: last post_ntaps-1 demodulated floats
@@ -1527,12 +1584,7 @@ extern "C" int sdr_process_iq(sdr_handle* h, const void* iq, size_t n, int is_de
         const long long Hp = c.post_ntaps - 1;
         float* cur = h->d_post_hist[h->post_hist_sel];
         float* nxt = h->d_post_hist[h->post_hist_sel ^ 1];
-        if (nout >= Hp)
-            HIPCHK(h, hipMemcpyAsync(nxt, h->d_tap + (nout - Hp), (size_t)Hp * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
-        else {
-            HIPCHK(h, hipMemcpyAsync(nxt, cur + nout, (size_t)(Hp - nout) * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
-            HIPCHK(h, hipMemcpyAsync(nxt + (Hp - nout), h->d_tap, (size_t)nout * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
-        }
+        HIPCHK(h, tail_update(h->stream, cur, h->d_tap, (size_t)Hp * sizeof(float), (size_t)nout * sizeof(float), nxt, h->tail_defer));
         h->post_hist_sel ^= 1;
     }
     // counters
