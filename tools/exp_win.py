@@ -19,7 +19,8 @@ for mode in sys.argv[6:] or ["win", "mfma", "valu"]:
     os.environ["SDR_FRONTEND"] = mode
     c = chain.Chain(2e6, decim=1, taps=taps, demod=chain.DEMOD_QUAD if demod == "quad" else chain.DEMOD_MAG2,
                     thr=(-0.2, 0.2) if demod == "quad" else (0.05, 0.15), keep_n=keep, max_batch=ncap, max_frames=4, max_samples=n,
-                    center_freq=float(os.environ.get("WIN_FC", "0")), input_format="cu8" if cu8 else "fc32")
+                    center_freq=float(os.environ.get("WIN_FC", "0")), input_format="cu8" if cu8 else "fc32",
+                    tap_demod=bool(os.environ.get("WIN_TAP")))
     c.set_stream(torch.cuda.current_stream().cuda_stream)
     for _ in range(3):
         c.batch_process(iq)
