@@ -694,7 +694,7 @@ def pfb_workload(torch, dev, skip_cpu, n=1 << 26, fs=20e6, steps=10):
     return out
 
 
-PMC_FILE = "r02_e_pmc.json"   # the committed FETCH_SIZE / WRITE_SIZE passes of the current kernels (tools/profile_round.sh)
+PMC_FILE = "r02_f_pmc.json"   # the committed FETCH_SIZE / WRITE_SIZE passes of the current kernels (tools/profile_round.sh)
 
 
 def progress(msg):
