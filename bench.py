@@ -39,7 +39,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # workload is timed twice, one stream first (its kernel times feed `roofline`), then overlapped (`ms_per_step`,
 # `value`); every step of either pass does all of its work and each pass ends with a device-wide synchronize.
 # SDR_BENCH_OVERLAP=0 skips the second pass.
-OVERLAP = os.environ.get("SDR_BENCH_OVERLAP", "1") != "0" and "ROCPROF_COUNTER_COLLECTION" not in os.environ   # --pmc runs one kernel at a time
+OVERLAP = os.environ.get("SDR_BENCH_OVERLAP", "1") != "0"
 FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32 vector peak = f32-input MFMA peak
 BYTES_PER_SAMPLE = 8.0 + 1.0 / DECIM  # complex64 in + sliced byte out
 
@@ -190,7 +190,7 @@ def fm_workload(torch, dev, skip_cpu, n=1 << 26, fs=2.4e6, steps=10):
     stream the kernels run on."""
     from sdr_amd import fm, synth
     m = 1 << 22
-    iq = synth.fm_iq(m, fs, f_off=200e3, seed=98)
+    iq = synth.fm_iq(m, fs, f_off=-200e3, seed=98)
     x1 = torch.from_numpy(iq.view(np.float32)).to(dev)
     x = x1.repeat(n // m, 1) if x1.dim() == 2 else x1.repeat(n // m)
     r = fm.FmRadio(samp_rate=fs, shift=200e3, max_samples=n)

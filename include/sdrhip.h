@@ -208,6 +208,13 @@ SDR_API int sdr_set_overlap(sdr_handle* h, int on);
 /* hipStream_t (as void*) that device-side results are ordered on: the result stream while sdr_set_overlap is
  * on, else the handle's stream. */
 SDR_API void* sdr_result_stream(sdr_handle* h);
+/* Diagnostics, non-blocking (hipStreamQuery / hipEventQuery; no counterpart in the reference): where the two
+ * streams of a handle stand.  state[0] handle stream idle, [1] result stream idle, [2] the front-end event
+ * reached, [3], [4] the two back-end events reached (1 yes, 0 not yet, -1 never recorded / no result stream),
+ * [5] the row set the last batch wrote, [6] the row set whose event was recorded last, [7] the result stream
+ * holds work the handle's stream has not been ordered behind.  May be called from another thread while a
+ * call on the handle blocks. */
+SDR_API int sdr_overlap_state(sdr_handle* h, int32_t state[8]);
 SDR_API const char* sdr_last_error(sdr_handle* h);
 
 /* ---- streaming entry points (state carried in the handle) -----------------
@@ -297,9 +304,14 @@ SDR_API int sdr_export_frames(sdr_handle* h, void* frames_dev, size_t frames_byt
  * prefilter, squelch, post-demod filter, channelizer, demod tap); the batch's
  * tables must fit the static array (about 60 KiB per capture of 2^18 samples at
  * decimation 50) and a row must stay below 32 KiB of sliced bytes, else
- * SDR_E_CAPACITY.  All calls on one GPU share that GPU's array: calls that overlap
- * on one GPU (different handles / streams) race -- serialise them.  The handle's
- * own results (sdr_fetch_*) are left as they were. */
+ * SDR_E_CAPACITY.  All calls on one GPU share that GPU's array, which keeps the
+ * last call's contents.  Calls on one stream are ordered by the stream; a call on
+ * another stream is queued behind the previous user's event on the device (one event
+ * per GPU, created at sdr_create: still nothing allocated on the call path), so
+ * direct calls from different handles / streams / threads serialise instead of
+ * racing.  NOT covered: a stream under graph capture records no such event -- replays
+ * of a captured call that overlap other users of the array on the same GPU race;
+ * order them yourself.  The handle's own results (sdr_fetch_*) are left as they were. */
 SDR_API int sdr_batch_process_static(sdr_handle* h, const void* iq_dev, size_t n_per_capture, size_t stride,
                                      int n_captures, int8_t* bits_dev, size_t bits_cap, sdr_frame* frames_dev,
                                      size_t frames_cap, int32_t* counts_dev, sdr_out* out);

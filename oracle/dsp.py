@@ -315,11 +315,11 @@ def ook_chain(iq, taps, D, gain, lo, hi, keep_n, fc=0.0, fs=1.0, return_mag=Fals
 
 
 def fm_radio_chain(iq, samp_rate=2e6, shift=200e3, volume=1.0, lpf=(2e6, 400e3, 200e3), quad_rate=500e3,
-                   audio_decimation=10, tau=75e-6, audio_resample=(48, 50)):
+                   audio_decimation=10, tau=75e-6, audio_resample=(48, 50), rotator="nco64"):
     """FM-Radio/FM-Radio.grc:2903-2964 block after block (each its own pass, as
     the GNU Radio scheduler runs it).  Returns the five stage outputs."""
     D = int(samp_rate / 500e3)
-    x = freq_xlating_fir(iq, [1.0], -shift, samp_rate, 1)
+    x = freq_xlating_fir(iq, [1.0], -shift, samp_rate, 1, rotator=rotator)   # "gr": GNU Radio's float recurrence
     y0 = fir_ccf(x, resampler_taps(1, D) if D > 1 else np.ones(1, np.float32), D)
     y1 = fir_ccf(y0, low_pass(1.0, lpf[0], lpf[1], lpf[2], WIN_BLACKMAN), 1)
     gain = np.float32(quad_rate / (2 * np.pi * 75e3))

@@ -155,7 +155,7 @@ EXPORTS = [
     "sdr_fm_last_error", "sdr_fm_reset",
     "sdr_pfb_create", "sdr_redecode", "sdr_set_input_format", "sdr_history_len", "sdr_seek", "sdr_segment_info_get", "sdr_export_bits",
     "sdr_batch_process_static", "sdr_static_scratch_bytes", "sdr_segment_info_rows", "sdr_batch_process_bits",
-    "sdr_redecode_multi", "sdr_fetch_frames_multi", "sdr_set_overlap", "sdr_result_stream",
+    "sdr_redecode_multi", "sdr_fetch_frames_multi", "sdr_set_overlap", "sdr_result_stream", "sdr_overlap_state",
 ]
 
 _lib = None
@@ -223,6 +223,8 @@ def load():
     L.sdr_set_overlap.argtypes = [H, C.c_int]
     L.sdr_result_stream.restype = C.c_void_p
     L.sdr_result_stream.argtypes = [H]
+    L.sdr_overlap_state.restype = C.c_int
+    L.sdr_overlap_state.argtypes = [H, C.POINTER(C.c_int32 * 8)]
     L.sdr_last_error.restype = C.c_char_p
     L.sdr_last_error.argtypes = [H]
     L.sdr_process_iq.restype = C.c_int

@@ -154,6 +154,13 @@ class Chain(object):
         """hipStream_t (int) that device-side results are ordered on (torch.cuda.ExternalStream takes it)."""
         return int(self._L.sdr_result_stream(self._h) or 0)
 
+    def overlap_state(self):
+        """sdr_overlap_state: non-blocking look at the handle's two streams and their events (8 ints, see
+        include/sdrhip.h); callable from another thread while a call on the handle blocks."""
+        st = (C.c_int32 * 8)()
+        _lib.check(self._h, self._L.sdr_overlap_state(self._h, C.byref(st)))
+        return list(st)
+
     # -- data path
     def _nsamp(self, keep, dev):
         """complex samples in a 1-D stream argument"""

@@ -46,10 +46,15 @@ struct RuleState {
 // Workgroup barrier that orders LDS accesses only: s_waitcnt lgkmcnt(0) (vmcnt and expcnt left alone; gfx9 encoding)
 // + s_barrier.  __syncthreads() also fences global memory (vmcnt(0)): a barrier inside a loop that keeps loads of
 // the next round in flight, or right behind output stores, then waits for an HBM round trip it does not need.
+// Both intrinsics are IntrNoMem to the optimizer, so the pair is bracketed by compiler-only memory clobbers: no LDS
+// load or store may be moved across it (no instruction is emitted for them, and vmcnt is still not waited on --
+// tests/test_codegen_guard.py checks the generated code).
 __device__ __forceinline__ void lds_only_barrier()
 {
+    asm volatile("" ::: "memory");
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
 }
 #endif
 

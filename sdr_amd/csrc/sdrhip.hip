@@ -169,10 +169,22 @@ static int fail(sdr_handle* h, int code, const std::string& msg)
 // ------------------------------------------------------------------ overlapped batches
 // Entry points that read or replace what a back end writes call ov_join first: h->stream waits for the last
 // event of the result stream, after which the handle behaves as if it had one stream.
+// SDR_OV_TRACE=1 (diagnostics, read once): every cross-stream record / wait of the overlap pattern on stderr
+static bool ov_trace()
+{
+    static const bool on = getenv("SDR_OV_TRACE") != nullptr;
+    return on;
+}
+#define OV_TRACE(...)                                 \
+    do {                                              \
+        if (ov_trace()) fprintf(stderr, __VA_ARGS__); \
+    } while (0)
+
 static int ov_join(sdr_handle* h)
 {
     if (h && h->ov_pending) {
         (void)hipSetDevice(h->device);
+        OV_TRACE("[ov %p] join: stream waits back[%d]\n", (void*)h, h->ov_last);
         HIPCHK(h, hipStreamWaitEvent(h->stream, h->ov_back[h->ov_last], 0));
         h->ov_pending = false;
     }
@@ -197,6 +209,7 @@ static int result_stream_begin(sdr_handle* h, hipStream_t* bs)
 {
     *bs = h->stream;
     if (!h->ov_call) return SDR_OK;
+    OV_TRACE("[ov %p] begin: record front on stream, bstream waits front\n", (void*)h);
     HIPCHK(h, hipEventRecord(h->ov_front, h->stream));
     HIPCHK(h, hipStreamWaitEvent(h->bstream, h->ov_front, 0));
     *bs = h->bstream;
@@ -205,6 +218,7 @@ static int result_stream_begin(sdr_handle* h, hipStream_t* bs)
 static int result_stream_end(sdr_handle* h)
 {
     if (!h->ov_call) return SDR_OK;
+    OV_TRACE("[ov %p] end: record back[%d] on bstream\n", (void*)h, h->ov_sel);
     HIPCHK(h, hipEventRecord(h->ov_back[h->ov_sel], h->bstream));
     h->ov_back_rec[h->ov_sel] = true;
     h->ov_last = h->ov_sel;
@@ -217,6 +231,7 @@ static int ov_next_buffers(sdr_handle* h)
     std::swap(h->d_bits, h->d_bits2);
     std::swap(h->d_tsum, h->d_tsum2);
     h->ov_sel ^= 1;
+    OV_TRACE("[ov %p] next buffers: pair %d%s\n", (void*)h, h->ov_sel, h->ov_back_rec[h->ov_sel] ? ", stream waits its back event" : "");
     if (h->ov_back_rec[h->ov_sel]) HIPCHK(h, hipStreamWaitEvent(h->stream, h->ov_back[h->ov_sel], 0));
     return SDR_OK;
 }
@@ -706,7 +721,9 @@ extern "C" int sdr_create(const sdr_chain_cfg* cfg, sdr_handle** out)
                                               : h->cfg.sample_rate / h->cfg.decim / h->cfg.keep_n;
         // rawBuffer may hold up to reset_limit worth of pending samples plus one call
         long long pend = (long long)(decoder_reset_limit(h->cfg.decoder) * 1e-6 * h->dec_rate) + 64;
-        if (B > 1) pend = 0;
+        // batches decode every capture from a fresh rawBuffer; 64 rows may be a one-capture channelizer handle,
+        // which streams (pfb_stream accumulates a stream decoder's rawBuffer in every channel row)
+        if (B > 1 && B != PFB_M) pend = 0;
         h->bits_stride = ((nb_max + pend + 63) / 64) * 64;
         HIPCHK(h, dev_alloc((void**)&h->d_bits, (size_t)(B * h->bits_stride)));
         HIPCHK(h, memset_done(h->d_bits, 0, (size_t)(B * h->bits_stride)));
@@ -896,9 +913,6 @@ extern "C" int sdr_set_overlap(sdr_handle* h, int on)
     (void)hipSetDevice(h->device);
     OV_JOIN(h);
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    // rocprofv3 counter collection runs one kernel at a time whatever the streams say, and its serialiser was
-    // seen to stall on this two-queue pattern (bench.py under --pmc): keep one stream there, results are the same
-    if (on && getenv("ROCPROF_COUNTER_COLLECTION")) on = 0;
     if (on && !h->bstream) {
         const size_t B = (size_t)h->cfg.max_batch;
         {
@@ -917,6 +931,27 @@ extern "C" int sdr_set_overlap(sdr_handle* h, int on)
         HIPCHK(h, dev_alloc((void**)&h->d_tsum2, B * (size_t)h->tsum_stride * sizeof(TileSum)));
     }
     h->overlap = on != 0;
+    return SDR_OK;
+}
+
+// Diagnostics: where the two streams of an overlapped handle stand, without blocking (hipStreamQuery /
+// hipEventQuery).  out[0] = handle stream idle, out[1] = result stream idle, out[2] = ov_front reached,
+// out[3], out[4] = ov_back[0], ov_back[1] reached (1 yes, 0 not yet, -1 never recorded / no second stream),
+// out[5] = pair the last batch wrote, out[6] = pair whose event was recorded last, out[7] = result stream holds
+// work the handle's stream has not been ordered behind.
+extern "C" int sdr_overlap_state(sdr_handle* h, int32_t out[8])
+{
+    if (!h || !out) return SDR_E_ARG;
+    (void)hipSetDevice(h->device);
+    auto q = [](hipError_t e) { return e == hipSuccess ? 1 : (e == hipErrorNotReady ? 0 : -2); };
+    out[0] = q(hipStreamQuery(h->stream));
+    out[1] = h->bstream ? q(hipStreamQuery(h->bstream)) : -1;
+    out[2] = h->ov_front ? q(hipEventQuery(h->ov_front)) : -1;
+    for (int i = 0; i < 2; ++i) out[3 + i] = (h->ov_back[i] && h->ov_back_rec[i]) ? q(hipEventQuery(h->ov_back[i])) : -1;
+    out[5] = h->ov_sel;
+    out[6] = h->ov_last;
+    out[7] = h->ov_pending ? 1 : 0;
+    (void)hipGetLastError();   // hipErrorNotReady is an answer, not a failure
     return SDR_OK;
 }
 
@@ -2064,6 +2099,15 @@ extern "C" int sdr_export_bits(sdr_handle* h, void* bits_dev, size_t cap_bytes, 
 #define SDR_STATIC_MAX_DEVICES 64
 static __device__ __align__(256) unsigned char scratch[SDR_STATIC_SCRATCH_BYTES];
 static unsigned char* g_scratch_ptr[SDR_STATIC_MAX_DEVICES];   // per device: that GPU's copy of the array
+// Every call on a GPU shares that GPU's array.  Calls on ONE stream are ordered by the stream; a call on another
+// stream (another handle, another thread) is queued behind the last user's event, so back-to-back calls from
+// different streams serialise on the device instead of racing.  Events are created once per device in
+// scratch_init (nothing is allocated on the call path).  Not covered: a stream under graph capture (an event
+// recorded there belongs to the graph and cannot order work outside it) -- replays of a captured call and direct
+// calls that overlap on one GPU are the caller's to order.
+static hipEvent_t g_scratch_ev[SDR_STATIC_MAX_DEVICES];
+static hipStream_t g_scratch_last[SDR_STATIC_MAX_DEVICES];
+static bool g_scratch_used[SDR_STATIC_MAX_DEVICES];
 static std::mutex g_scratch_mu;
 
 static int scratch_init(sdr_handle* h)
@@ -2075,6 +2119,7 @@ static int scratch_init(sdr_handle* h)
     void* ptr = nullptr;
     HIPCHK(h, hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));    // the handle's device is current (sdr_create)
     if (!ptr) return fail(h, SDR_E_HIP, "hipGetSymbolAddress(scratch) returned a null address");
+    HIPCHK(h, hipEventCreateWithFlags(&g_scratch_ev[dev], hipEventDisableTiming));
     g_scratch_ptr[dev] = static_cast<unsigned char*>(ptr);
     return SDR_OK;
 }
@@ -2117,12 +2162,20 @@ extern "C" int sdr_batch_process_static(sdr_handle* h, const void* iq_dev, size_
     const size_t o_cur = carve((size_t)(B * SDR_CUR_CAP) * sizeof(double));
     const size_t o_st = carve((size_t)B * sizeof(DecState));
     const size_t o_frames = carve((size_t)(B * c.max_frames) * sizeof(sdr_frame));
-    if (off > SDR_STATIC_SCRATCH_BYTES || bstride >= SDR_SEG_MIN_ROW)
+    if (off > SDR_STATIC_SCRATCH_BYTES || bstride >= h->seg_min_row)
         return fail(h, SDR_E_CAPACITY, "sdr_batch_process_static: this batch needs " + std::to_string(off) + " bytes of scratch, the static array holds " +
-                                       std::to_string(SDR_STATIC_SCRATCH_BYTES) + " (and rows must stay below 32 KiB of sliced bytes); use sdr_batch_process");
+                                       std::to_string(SDR_STATIC_SCRATCH_BYTES) + " (and rows must stay below " + std::to_string(h->seg_min_row) +
+                                       " sliced bytes: longer ones take the segment tables); use sdr_batch_process");
     if (bits_cap < (size_t)(B * g.ne) || frames_cap < (size_t)(B * c.max_frames))
         return fail(h, SDR_E_CAPACITY, "sdr_batch_process_static: output buffer too small");
     unsigned char* const base = g_scratch_ptr[h->device];   // never the array's name: that is a host-side stand-in
+    // the array's last user on this GPU, if it was another stream: this call's work waits for it on the device
+    std::lock_guard<std::mutex> scratch_lk(g_scratch_mu);
+    hipStreamCaptureStatus cap_st = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(h->stream, &cap_st);
+    const bool capturing = cap_st != hipStreamCaptureStatusNone;
+    if (!capturing && g_scratch_used[h->device] && g_scratch_last[h->device] != h->stream)
+        HIPCHK(h, hipStreamWaitEvent(h->stream, g_scratch_ev[h->device], 0));
     // what must start at zero: row padding behind the sliced bytes, the frame table (record padding bytes)
     HIPCHK(h, hipMemsetAsync(base + o_bits, 0, (size_t)(B * bstride), h->stream));
     HIPCHK(h, hipMemsetAsync(base + o_frames, 0, (size_t)(B * c.max_frames) * sizeof(sdr_frame), h->stream));
@@ -2166,6 +2219,12 @@ extern "C" int sdr_batch_process_static(sdr_handle* h, const void* iq_dev, size_
     h->d_runs = sv.runs; h->d_runs_seg = sv.runs_seg; h->d_runs_n = sv.runs_n; h->runs_cap = sv.rcap;
     h->d_cur = sv.cur; h->d_st = sv.st; h->d_frames = sv.frames; h->out_count = sv.out_count; h->profile = sv.profile;
     h->runs_valid = false;   // the handle's run table does not describe what its next sdr_redecode would expect
+    if (!capturing) {   // whatever was queued (also by a call that failed half way) is what the next user waits for
+        if (hipEventRecord(g_scratch_ev[h->device], h->stream) == hipSuccess) {
+            g_scratch_used[h->device] = true;
+            g_scratch_last[h->device] = h->stream;
+        }
+    }
     if (r) return r;
     HIPCHK(h, hipGetLastError());
     return finish_out(h, out, (unsigned long long)n * ncap, g.ne);

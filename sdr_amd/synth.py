@@ -392,7 +392,8 @@ def _random_ts33c_fields(rng):
 
 
 def fm_iq(n, fs, f_off=200e3, tones=((1e3, 0.5), (19e3, 0.1)), dev=75e3, sigma=0.01, seed=98):
-    """WBFM test signal: sum of tones frequency-modulated +-dev at f_off."""
+    """WBFM test signal: sum of tones frequency-modulated +-dev at f_off.  FM-Radio.grc translates with
+    center_freq = -shift (FM-Radio/FM-Radio.grc:621-666), i.e. the station sits at f_off = -shift of the tuner."""
     rng = np.random.default_rng(seed)
     t = np.arange(n, dtype=np.float64) / fs
     m = np.zeros(n)

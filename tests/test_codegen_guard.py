@@ -79,3 +79,16 @@ def test_hot_kernels_use_no_scratch_memory(device_asm):
         blk = device_asm[i:device_asm.index(".end_amdhsa_kernel", i)]
         m = re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", blk)
         assert m and int(m.group(1)) == 0, "%s uses %s bytes of scratch per lane" % (sym, m.group(1) if m else "?")
+
+
+def test_lds_only_barriers_do_not_wait_for_global_memory(device_asm):
+    """k_frontend_mfma2's phase loop keeps the next tile's 16-B loads in flight across its barriers
+    (lds_only_barrier: s_waitcnt lgkmcnt(0) + s_barrier between compiler-only memory clobbers).  A vmcnt wait in
+    front of one of them would put an HBM round trip into every phase with identical results."""
+    lines = _kernel_body(device_asm, "_Z16k_frontend_mfma211FrontParamsi")
+    bars = [k for k, l in enumerate(lines) if re.search(r"\bs_barrier\b", l)]
+    assert len(bars) >= 2
+    for k in bars:
+        near = [l.strip() for l in lines[max(0, k - 6):k] if "s_waitcnt" in l]
+        assert near, "no s_waitcnt in front of an s_barrier: LDS traffic may still be in flight"
+        assert not [l for l in near if "vmcnt" in l], "a barrier of the phase loop waits for global memory: %s" % near

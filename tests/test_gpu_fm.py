@@ -23,7 +23,7 @@ def _cmp(got, want, exact):
 
 @pytest.mark.parametrize("fs,n", [(2.4e6, 1 << 20), (2e6, 300000)])
 def test_fm_chain_stages(fs, n):
-    iq = synth.fm_iq(n, fs, f_off=200e3, seed=98)
+    iq = synth.fm_iq(n, fs, f_off=-200e3, seed=98)
     want = odsp.fm_radio_chain(iq, samp_rate=fs, shift=200e3, volume=0.8)
     with fm.FmRadio(samp_rate=fs, shift=200e3, volume=0.8, max_samples=n) as r:
         na = r.process(iq)
@@ -40,7 +40,7 @@ def test_fm_chain_streaming_chunks_equal_one_shot():
     stage, shorter than the filters, empty) through one object give the oracle's stage outputs, and reset()
     really returns to stream start.  FIR / discriminator stages bit-identical, IIR / resampler <= 1e-5."""
     fs, n = 2.4e6, 600000
-    iq = synth.fm_iq(n, fs, f_off=200e3, seed=7)
+    iq = synth.fm_iq(n, fs, f_off=-200e3, seed=7)
     want = odsp.fm_radio_chain(iq, samp_rate=fs, shift=200e3, volume=0.8)
     cuts = [0, 1, 3, 4, 5, 39, 40, 41, 1000, 1000, 77777, 77778, 300001, 512345, n]
     with fm.FmRadio(samp_rate=fs, shift=200e3, volume=0.8, max_samples=n) as r:
@@ -67,7 +67,7 @@ def test_fm_audio_fir_vector_form(monkeypatch):
     """The audio FIR has two forms (matrix cores; vector ALUs when the tile does not fit LDS or the filter is
     short): force the second (SDR_FM_AUDIO=valu, read at create) and hold it to the same bits."""
     fs, n = 2e6, 300000
-    iq = synth.fm_iq(n, fs, f_off=200e3, seed=5)
+    iq = synth.fm_iq(n, fs, f_off=-200e3, seed=5)
     want = odsp.fm_radio_chain(iq, samp_rate=fs, shift=200e3, volume=0.8)
     monkeypatch.setenv("SDR_FM_AUDIO", "valu")
     with fm.FmRadio(samp_rate=fs, shift=200e3, volume=0.8, max_samples=n) as r:
@@ -84,7 +84,7 @@ def test_fm_chain_repeats_bit_for_bit():
     written its share: about one run in twenty had a few thousand wrong samples in stage 0.)"""
     torch = pytest.importorskip("torch")
     fs, m = 2.4e6, 1 << 21
-    iq = synth.fm_iq(m, fs, f_off=200e3, seed=7)
+    iq = synth.fm_iq(m, fs, f_off=-200e3, seed=7)
     big = torch.from_numpy(iq.view(np.float32)).to("cuda:0").repeat(8, 1)
     half = m // 2 + 4321
     with fm.FmRadio(samp_rate=fs, shift=200e3, max_samples=8 * m) as r:

@@ -121,3 +121,30 @@ def test_pfb_segments_stitched_equal_single_pass():
         c.batch_process_bits(stream)
         two = [(f.capture, f.status, f.packet(), f.end_pos) for f in c.fetch_frames()]
     assert one == two and [f[2] for f in one if f[1] == 0] == [pkt, pkt]
+
+
+def test_pfb_streaming_short_chunk_then_max_samples_chunk():
+    """A chunk shorter than the stream decoder's reset limit leaves its bytes pending in every channel row's
+    rawBuffer (TS33C/stream_decoder.py:44-47); a max_samples chunk behind it must still fit -- the header promises
+    chunks of any length.  max_samples is chosen so that the row stride had 2 bytes of slack before round 3
+    (the pending margin was dropped for every handle with more than one row)."""
+    keep = 16
+    n_max = (1 << 22) - 2048
+    rate = FS / M / keep
+    short = 25 * keep * M                       # 25 bytes per row: 1280 us < reset_limit 1550 us
+    x, pkt, code = _capture(short + n_max, keep, seed=23)
+    taps = _proto()
+    want = _slice_oracle(odsp.pfb_channelize(x, taps, M), 1.0, 0.05, 0.15, keep)
+    with chain.Chain(FS, taps=taps, keep_n=keep, decoder=chain.DEC_TS33C, decoder_rate=rate, max_samples=n_max, max_frames=64,
+                     channels=M) as c:
+        c.process_iq(x[:short])
+        b1 = c.fetch_bits().reshape(M, -1)
+        assert b1.shape[1] == 25 and not c.fetch_frames()
+        c.process_iq(x[short:])
+        b2 = c.fetch_bits().reshape(M, -1)
+        frames = [(f.capture, f.status, f.packet()) for f in c.fetch_frames()]
+    assert np.array_equal(np.concatenate([b1, b2], axis=1), want)
+    o = odec.TS33CStreamDecoder(sample_rate=rate)
+    o.work([want[7][:25]])
+    o.work([want[7][25:]])
+    assert [f[2] for f in frames if f[1] == 0 and f[0] == 7] == [f["packet"] for f in o.frames if f["status"] == "ok"] == [pkt, pkt]

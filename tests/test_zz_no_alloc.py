@@ -112,6 +112,35 @@ def test_static_entry_point_under_graph_capture():
         del g
 
 
+def test_static_entry_point_two_handles_two_streams_back_to_back():
+    """Every call on a GPU shares that GPU's static array.  Two handles on two different streams, called back to
+    back with nothing between them on the host: the second call is queued behind the first one's event on the
+    device (round 3), so both give what sdr_batch_process gives -- before that they raced."""
+    fs, D, max_frames = 1e6, 50, 4
+    taps = chain.low_pass(1.0, fs, 20e3, 40e3)
+    dev = torch.device("cuda", 0)
+    ncap, n = 28, 1 << 18
+    kw = dict(decim=D, center_freq=100e3, taps=taps, decoder=chain.DEC_TS33C, max_batch=32, max_frames=max_frames, max_samples=n)
+    xs = [torch.from_numpy(_batch(ncap, n, fs, seed).view(np.float32).reshape(ncap, n, 2)).to(dev) for seed in (41, 42)]
+    nb = n // D
+    with chain.Chain(fs, **kw) as ref, chain.Chain(fs, **kw) as a, chain.Chain(fs, **kw) as b:
+        want = [_reference(ref, x, max_frames) for x in xs]
+        outs = [(torch.zeros(ncap * nb, dtype=torch.uint8, device=dev),
+                 torch.zeros(ncap * max_frames * C.sizeof(_lib.Frame), dtype=torch.uint8, device=dev),
+                 torch.zeros(ncap, dtype=torch.int32, device=dev)) for _ in xs]
+        torch.cuda.synchronize()
+        for rep in range(6):                       # each handle has its own stream (sdr_create)
+            for c, x, o in ((a, xs[0], outs[0]), (b, xs[1], outs[1])):
+                c.batch_process_static(x, *o)
+        a.synchronize()
+        b.synchronize()
+        for (wnb, wbits, wrec, wcnt), (bits, rec, cnt) in zip(want, outs):
+            assert wnb == nb and wcnt.sum() >= ncap
+            assert np.array_equal(cnt.cpu().numpy(), wcnt)
+            assert np.array_equal(bits.cpu().numpy(), wbits)
+            assert np.array_equal(rec.cpu().numpy(), wrec)
+
+
 def test_zz_guard_bands_behind_device_buffers():
     """Collected last.  Under SDR_POISON=1 every device buffer the library allocated had a 512-byte guard band
     behind it, checked when the buffer was freed: none may have been written.  (Without the switch: nothing to
