@@ -122,7 +122,27 @@ def cpu_worker(path, first, count, budget_s):
     print(json.dumps({"done": done, "seconds": used, "frames": frames}))
 
 
-def cpu_baseline(iq_gpu, taps, budget_s=10.0):
+def worker_env():
+    """Environment of the CPU-baseline worker processes: they never touch the GPU, so a profiler wrapped around
+    this command (rocprofv3 sets LD_PRELOAD / ROCP* / ROCPROF* for its tool library) is not inherited -- its
+    library would otherwise run in every worker and write trace files of its own into the same directory."""
+    env = {k: v for k, v in os.environ.items() if not (k.startswith("ROCP") or k.startswith("ROCPROF") or k == "HSA_TOOLS_LIB")}
+    if "LD_PRELOAD" in env:
+        keep = [x for x in env["LD_PRELOAD"].replace(":", " ").split() if "rocprof" not in os.path.basename(x).lower()]
+        if keep:
+            env["LD_PRELOAD"] = ":".join(keep)
+        else:
+            del env["LD_PRELOAD"]
+    env["OMP_NUM_THREADS"] = "1"
+    return env
+
+
+def cpu_sample(iq_gpu):
+    """the captures the CPU baseline runs over: two per host core from the head of this rank's batch, on the host"""
+    return iq_gpu[:min(iq_gpu.shape[0], 2 * host_cores())].cpu().numpy()
+
+
+def cpu_baseline(sample, taps, budget_s=None):
     """The oracle (C restatement of the GNU Radio blocks + numpy restatement of TS33C/stream_decoder.py) over a
     bounded sample of the same captures: one host core (the scalar port, `value`) and ALL the job's host
     cores (one worker process per core over disjoint captures, `all_cores`).  A stand-in for the reference
@@ -131,10 +151,10 @@ def cpu_baseline(iq_gpu, taps, budget_s=10.0):
     import tempfile
     from oracle import decoders as odec
     from oracle import dsp as odsp
-    ncap = iq_gpu.shape[0]
+    if budget_s is None:
+        budget_s = float(os.environ.get("SDR_BENCH_CPU_BUDGET", "10"))
     cores = host_cores()
-    nsample = min(ncap, 2 * cores)
-    sample = iq_gpu[:nsample].cpu().numpy()
+    nsample = sample.shape[0]
 
     def one_pass(k=[0]):
         x = sample[k[0] % nsample].view(np.complex64).reshape(-1)
@@ -156,8 +176,7 @@ def cpu_baseline(iq_gpu, taps, budget_s=10.0):
         np.save(path, sample)
         np.save(path + ".taps.npy", np.asarray(taps, np.float32))
         per = max(1, nsample // cores)
-        env = dict(os.environ)
-        env["OMP_NUM_THREADS"] = "1"
+        env = worker_env()
         t0 = time.perf_counter()
         procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", path, str((w * per) % nsample),
                                    str(per), str(budget_s)], stdout=subprocess.PIPE, env=env) for w in range(cores)]
@@ -215,13 +234,14 @@ def fm_workload(torch, dev, skip_cpu, n=1 << 26, fs=2.4e6, steps=10):
     # 131-tap resampler /4, 33-tap LPF at fs/4, 771-tap audio filter /10 at fs/4, 821-tap 24/25 polyphase resampler
     fps = 4.0 * 131 / 4 + 4.0 * 33 / 4 + 2.0 * 771 / 40 + 2.0 * (821 / 24.0) * (24.0 / 25.0) / 40
     tf = fps * n / (gpu_ms * 1e-3) / 1e12
+    fm_traffic, fm_traffic_src = pmc_traffic("fm chain", "samples=2^%d" % int(np.log2(n)))   # sum over the chain's kernels
     out = {"value": round(n / dt / 1e6, 1), "unit": "Msps", "ms_per_step": round(dt * 1e3, 4), "samples": n,
            "sample_rate": fs, "audio_samples": int(na),
            "chain": "xlating->resample 1/4->lpf->quadrature_demod->audio fir /10->deemph 75us->resample 24/25 (streaming state carried)",
            "roofline": {"bound": "mfma", "kernel": "whole chain: k_frontend_mfma (rotate + 131 taps /4) + k_frontend_win (33 taps, "
                         "discriminator) + k_fir_fff_mfma (771 taps /10) + k_deemph_warm + k_resample_fff",
                         "achieved": round(tf, 1), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(tf / FP32_PEAK_TFLOPS, 4), "traffic": None, "kernel_ms": round(gpu_ms, 4),
+                        "frac": round(tf / FP32_PEAK_TFLOPS, 4), "traffic": fm_traffic, "traffic_source": fm_traffic_src, "kernel_ms": round(gpu_ms, 4),
                         "flops_per_launch": fps * n, "hbm_achieved_gbs": round(ach, 1), "hbm_frac": round(ach / HBM_PEAK_GBS, 4),
                         "bytes_per_launch": bps * n,
                         "note": "%.0f algorithmic flop per 8.08 algorithmic bytes (SURVEY 8d) is above the fp32 ridge (157.3 TF / "
@@ -280,12 +300,14 @@ def r_shape_workload(torch, dev, skip_cpu, ncap=64, n=1 << 19, fs=2e6, steps=20)
         raise SystemExit("R shape: only %d of %d captures decoded to the transmitted packets" % (n_ok, ncap))
     fk = float(np.mean(front_ms))
     flops = 4.0 * taps.size * ncap * n
+    r_traffic, r_traffic_src = pmc_traffic("k_frontend_win r_shape", "captures=%d" % ncap)
     out = {"value": round(ncap * n / dt / 1e6, 1), "unit": "Msps", "ms_per_step": round(dt * 1e3, 4),
            "captures": ncap, "samples_per_capture": n, "sample_rate": fs, "ntaps": int(taps.size), "decim": 1,
            "keep_n": 100, "chain": "fir_filter_ccf->mag2->threshold->slicer->keep_one_in_n->ts33c_decoder",
            "roofline": {"bound": "mfma", "kernel": "k_frontend_win", "achieved": round(flops / (fk * 1e-3) / 1e12, 1),
                         "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(flops / (fk * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4), "traffic": None,
+                        "frac": round(flops / (fk * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4),
+                        "traffic": r_traffic, "traffic_source": r_traffic_src,
                         "kernel_ms": round(fk, 4), "backend_kernel_ms": round(float(np.mean(back_ms)), 4),
                         "flops_per_launch": flops, "note": "algorithmic flops = 4*ntaps per input sample (real taps); peak = the f32 "
                         "FMA rate (packed VALU = f32-input MFMA, 157.3 TF); the sliding-window VALU kernel issues exactly "
@@ -348,7 +370,7 @@ def cu8_workload(torch, dev, iq, pkts, taps, steps=20):
             "captures": ncap, "samples_per_capture": n, "input": "cu8 (u8 I, u8 Q), (x-127.4)/128 while staging",
             "roofline": {"bound": "hbm", "kernel": "k_frontend_raw8", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                         "traffic": pmc_traffic("k_frontend_raw8 cu8", "captures_per_gpu=%d" % ncap)[0],
+                         **traffic_fields("k_frontend_raw8 cu8", "captures_per_gpu=%d" % ncap),
                          "kernel_ms": round(fk, 4), "backend_kernel_ms": round(float(np.mean(back_ms)), 4),
                          "bytes_per_launch": bps * ncap * n,
                          "note": "2.02 algorithmic bytes per sample: the kernel is latency/issue bound, not HBM "
@@ -415,7 +437,7 @@ def tfa_fsk_workload(torch, dev, skip_cpu, ncap=64, n=1 << 20, fs=2e6, dev_hz=60
            "chain": "fir_filter_ccf->quadrature_demod->threshold->slicer->tfa_stream_decoder",
            "roofline": {"bound": "hbm", "kernel": "k_frontend_win", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                        "traffic": pmc_traffic("k_frontend_win tfa", "captures=%d" % ncap)[0], "kernel_ms": round(fk, 4),
+                        **traffic_fields("k_frontend_win tfa", "captures=%d" % ncap), "kernel_ms": round(fk, 4),
                         "backend_kernel_ms": round(float(np.mean(back_ms)), 4), "bytes_per_launch": bps * ncap * n,
                         "note": "27 taps at decimation 1 + one fast_atan2f per sample: 108 + ~90 flop-equivalents per 9 bytes, "
                                 "bound by VALU instruction issue (profiles/r02_a_win_sq.csv), not by HBM"},
@@ -540,7 +562,7 @@ def mixed_emitters_workload(torch, dev, skip_cpu, ncap=1250, n=N_PER_CAPTURE, fs
            "emitters": "somfy RTS / berner / mumbi, one per capture", "decoders_per_capture": 3,
            "chain": "xlating_fir->mag2->threshold->slicer->{somfy, berner, mumbi} rule decoders",
            "roofline": {"bound": "hbm", "kernel": "k_frontend<true, false>", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "kernel_ms": round(fk, 4),
+                        "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": _src, "kernel_ms": round(fk, 4),
                         "backend_kernel_ms": round(bk, 4), "bytes_per_launch": bps * ncap * n},
            "verified": "every capture decodes to its transmitted payload under its own decoder"}
     if not skip_cpu:
@@ -670,7 +692,7 @@ def pfb_workload(torch, dev, skip_cpu, n=1 << 26, fs=20e6, steps=10):
            "decoder_passes_per_step": 4, "decoder_launches_per_step": 2,
            "roofline": {"bound": "hbm", "kernel": "k_pfb<8>", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                        "traffic": pmc_traffic("k_pfb<8>", "samples=2^%d" % int(np.log2(n)))[0],
+                        **traffic_fields("k_pfb<8>", "samples=2^%d" % int(np.log2(n))),
                         "kernel_ms": round(fk, 4), "backend_kernel_ms": round(float(np.mean(back_ms)), 4),
                         "bytes_per_launch": bps * n},
            "verified": "the 3 TS33C frames decode in channel 5, the berner code in channel 40, the mumbi code in "
@@ -694,7 +716,112 @@ def pfb_workload(torch, dev, skip_cpu, n=1 << 26, fs=20e6, steps=10):
     return out
 
 
-PMC_FILE = "r02_f_pmc.json"   # the committed FETCH_SIZE / WRITE_SIZE passes of the current kernels (tools/profile_round.sh)
+def pfb_segments_workload(torch, dist, dev, rank, world, n=1 << 26, fs=20e6, steps=5):
+    """BASELINE.json configs[4] as worded -- "20 Msps capture channelized into 64 sub-bands, all sensor decoders per
+    channel on 8 GPUs" -- for ONE capture: rank r takes the r-th contiguous segment (boundaries multiples of
+    64 * keep_n) with the channelizer's FIR-history halo in front of it (sdr_seek), channelizes and slices it; the
+    per-row threshold summaries and the sliced rows (1/(64*16) byte per input sample and channel) are gathered
+    over RCCL (segments.gather_rows: two all_gathers); the 64 stitched rows are dealt out to the ranks and decoded
+    (sdr_batch_process_bits), and the frame records are gathered as in the headline.  Every step does all of
+    that; strong scaling (the capture is fixed, the segment shrinks with the rank count).  Verified on rank 0
+    against ONE sdr_batch_process pass over the whole capture: same stitched bytes, same frames."""
+    from sdr_amd import chain, segments, _lib
+    from sdr_amd import dist as sdist
+    M, keep, max_frames = 64, 16, 64
+    rate = fs / M / keep
+    iq, sent = make_wideband(torch, dev, n, fs, M)      # same seed on every rank: every rank holds the capture
+    taps = chain.low_pass(1.0, fs, 100e3, 100e3)
+    a, b = segments.segment_bounds(n, world, M * keep)[rank]
+    front = chain.Chain(fs, taps=taps, keep_n=keep, decoder=chain.DEC_NONE, max_samples=max(b - a, 1), channels=M)
+    dec = chain.Chain(fs, taps=taps, keep_n=keep, decoder=chain.DEC_TS33C, decoder_rate=rate, max_samples=n,
+                      max_frames=max_frames, channels=M)
+    for c in (front, dec):
+        c.set_stream(torch.cuda.current_stream().cuda_stream)
+    H = front.history_len()
+    per = -(-M // world)
+    r0, r1 = min(M, rank * per), min(M, (rank + 1) * per)
+    rec = torch.zeros(per * max_frames * sdist.FRAME_BYTES, dtype=torch.uint8, device=dev)
+    cnt = torch.zeros(per, dtype=torch.int32, device=dev)
+    res = {}
+
+    def step():
+        lo = max(0, a - H)
+        front.seek(a, iq[lo:a] if a > lo else None)
+        front.process_iq(iq[a:b])
+        infos = front.segment_info_rows()
+        nb = int(infos[0].n_bits)
+        bits = torch.zeros((M, max(nb, 1)), dtype=torch.uint8, device=dev)
+        front.export_bits(bits)
+        stream, _off = segments.gather_rows(bits, nb, [i.n_undetermined for i in infos], [i.has_event for i in infos],
+                                            [i.last_state for i in infos], world)
+        rec.zero_()
+        cnt.zero_()
+        if r1 > r0:
+            dec.batch_process_bits(stream[r0:r1])
+            dec.export_frames(rec, cnt)
+        res["stream"] = stream
+        res["gathered"] = sdist.gather_frames(rec, cnt, world)
+
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item()) / steps
+    out = None
+    if rank == 0:
+        all_rec, all_cnt = res["gathered"]
+        got = []
+        recs = np.ascontiguousarray(all_rec.cpu().numpy())
+        cnts = all_cnt.cpu().numpy()
+        for g in range(cnts.size):
+            r, i = divmod(g, per)
+            row = r * per + i
+            for k in range(int(cnts[g])):
+                off = (g * max_frames + k) * sdist.FRAME_BYTES
+                f = _lib.Frame.from_buffer_copy(recs[off:off + sdist.FRAME_BYTES].tobytes())
+                got.append((row, f.status, f.packet(), int(f.end_pos)))
+        whole = chain.Chain(fs, taps=taps, keep_n=keep, decoder=chain.DEC_TS33C, decoder_rate=rate, max_samples=n,
+                            max_frames=max_frames, channels=M)
+        whole.batch_process(iq.reshape(1, n, 2))
+        want = [(f.capture, f.status, f.packet(), int(f.end_pos)) for f in whole.fetch_frames()]
+        want_bits = whole.fetch_bits().reshape(M, -1)
+        whole.close()
+        if not np.array_equal(res["stream"].cpu().numpy().view(np.int8), want_bits):
+            raise SystemExit("pfb segments: stitched rows differ from the single pass")
+        if got != want:
+            raise SystemExit("pfb segments: frames differ from the single pass: %s vs %s" % (got[:4], want[:4]))
+        ch, pkt = sent["ts33c"]
+        good = [g_ for g_ in got if g_[1] == _lib.FRAME_OK]
+        if [g_[0] for g_ in good] != [ch] * 3 or [g_[2] for g_ in good] != [pkt] * 3:
+            raise SystemExit("pfb segments: expected the 3 transmitted TS33C frames in channel %d" % ch)
+        out = {"value": round(n / dt / 1e6, 1), "unit": "Msps", "ms_per_step": round(dt * 1e3, 4), "samples": n,
+               "sample_rate": fs, "channels": M, "n_gpus": world, "scaling": "strong", "segment_samples": b - a,
+               "halo_samples": H, "keep_n": keep,
+               "chain": "per rank: sdr_seek(halo) -> pfb64 -> mag2 -> threshold -> slicer -> keep_one_in_n on its segment; "
+                        "all_gather of per-row threshold summaries and sliced rows; rows dealt out -> ts33c decoder; all_gather of frame records",
+               "collective_bytes_per_step": int(world * (3 * M + 1) * 8 + world * M * max(16, -(-((b - a) // (M * keep)) // 16) * 16)
+                                                + world * (rec.numel() + 4 * cnt.numel())),
+               "verified": "stitched rows and frame records equal ONE sdr_batch_process pass over the whole capture on rank 0; "
+                           "the 3 transmitted TS33C frames decode in channel %d" % ch,
+               "note": "host-orchestrated (seek, summaries read back, two all_gathers, decode, frame gather per step): "
+                       "latency-bound, the figure of merit is that the segmented capture decodes to what one pass gives"}
+    front.close()
+    dec.close()
+    del iq
+    torch.cuda.empty_cache()
+    return out
+
+
+PMC_FILE = "r03_b_pmc.json"   # the committed FETCH_SIZE / WRITE_SIZE passes of the current kernels (tools/profile_round.sh)
 
 
 def progress(msg):
@@ -728,19 +855,55 @@ def overlapped_pass(torch, c, step, steps, out, units, per=1, warm=3):
     out["roofline"]["kernel_ms_overlapped"] = round(float(np.mean(front_ms[0::per])), 4)
 
 
+_PMC_CACHE = {}
+
+
+def _pmc_file():
+    """profiles/<PMC_FILE> once per process, plus whether the kernel sources are still the ones the passes ran on"""
+    if "rec" not in _PMC_CACHE:
+        root = os.path.dirname(os.path.abspath(__file__))
+        try:
+            with open(os.path.join(root, "profiles", PMC_FILE)) as f:
+                rec = json.load(f)
+        except (OSError, ValueError):
+            rec = {}
+        fresh = None
+        if rec.get("csrc_sha256"):
+            import hashlib
+            h = hashlib.sha256()
+            d = os.path.join(root, "sdr_amd", "csrc")
+            for name in sorted(os.listdir(d)):
+                if name.endswith((".h", ".hip")):
+                    h.update(name.encode())
+                    h.update(open(os.path.join(d, name), "rb").read())
+            fresh = h.hexdigest() == rec["csrc_sha256"]
+        _PMC_CACHE["rec"], _PMC_CACHE["fresh"] = rec, fresh
+    return _PMC_CACHE["rec"], _PMC_CACHE["fresh"]
+
+
+def traffic_fields(kernel_key, workload_tag):
+    t, src = pmc_traffic(kernel_key, workload_tag)
+    return {"traffic": t, "traffic_source": src}
+
+
 def pmc_traffic(kernel_key, workload_tag):
     """HBM bytes per launch of one kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
     WRITE_SIZE over this same command; counters cannot be read from inside the process).  None if the
-    committed workload differs from the one being run."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", PMC_FILE)
+    committed workload differs from the one being run.  The source string says whether the kernel sources
+    (sdr_amd/csrc) are byte for byte the ones the passes ran on -- if not, the figure describes an older kernel."""
+    rec, fresh = _pmc_file()
     try:
-        with open(path) as f:
-            rec = json.load(f)["kernels"][kernel_key]
-    except (OSError, KeyError, ValueError):
+        k = rec["kernels"][kernel_key]
+    except KeyError:
         return None, None
-    if workload_tag not in rec.get("workload", ""):
+    if workload_tag not in k.get("workload", ""):
         return None, None
-    return int(rec["hbm_bytes"]), "profiles/" + PMC_FILE
+    src = "profiles/" + PMC_FILE
+    if fresh is True:
+        src += " (kernel sources unchanged since those passes)"
+    elif fresh is False:
+        src += " (STALE: sdr_amd/csrc changed since those passes)"
+    return int(k["hbm_bytes"]), src
 
 
 def launch_ranks(n, argv, rehearsal):
@@ -784,6 +947,12 @@ def launch_ranks(n, argv, rehearsal):
     return rc
 
 
+def _oracle_low_pass():
+    """the headline's channel filter from the oracle's firdes (the rehearsal has no GPU library to ask)"""
+    from oracle import dsp as odsp
+    return odsp.low_pass(1.0, FS, 20e3, 40e3)
+
+
 def rehearsal_main(args, rank, world):
     """SDR_BENCH_REHEARSAL=gloo: the multi-rank skeleton of this file (rendezvous, frame-table gather, barriers,
     max over ranks, rank 0's line) on CPU ranks with made-up frame tables and NO chain work -- what
@@ -804,12 +973,25 @@ def rehearsal_main(args, rank, world):
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     if int(all_cnt.sum()) != 2 * ncap * world or not bool(torch.equal(all_rec[rank * rec.numel():(rank + 1) * rec.numel()], rec)):
         raise SystemExit("rank %d: rehearsal gather wrong" % rank)
-    if rank == 0:
-        print(json.dumps({"metric": "IQ Msps through filter+demod+slice+decode (whole job)", "value": None, "unit": "Msps",
-                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                          "ms_per_step": round(float(t.item()) / max(args.steps, 1) * 1e3, 4), "higher_is_better": True,
-                          "scaling": "weak", "vs_baseline": None, "rehearsal": "gloo ranks on CPU, no chain work, nothing measured"}))
+    # the per-rank kernel means travel as in the real run (one all_gather of a float per rank); made up here
+    allk = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+    dist.all_gather(allk, torch.tensor([0.5 + 0.01 * rank], dtype=torch.float64))
+    rank_fk = [float(v.item()) for v in allk]
     dist.destroy_process_group()
+    if rank == 0:
+        line = {"metric": "IQ Msps through filter+demod+slice+decode (whole job)", "value": None, "unit": "Msps",
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(float(t.item()) / max(args.steps, 1) * 1e3, 4), "higher_is_better": True,
+                "scaling": "weak", "vs_baseline": None, "rehearsal": "gloo ranks on CPU, no chain work, nothing measured",
+                "roofline": {"kernel_ms_per_rank": rank_fk, "frac_min": None, "frac_max": None}, "cpu_baseline": None}
+        if not args.no_cpu_baseline:
+            # the CPU leg as in the real run: rank 0 alone, after the process group is gone, on captures made on the host
+            from sdr_amd import synth
+            caps = np.stack([synth.ts33c_capture(N_PER_CAPTURE, FS, seed=33 + i, f_off=F_OFF)[0].view(np.float32).reshape(-1, 2)
+                             for i in range(2)])
+            taps = np.asarray(_oracle_low_pass(), np.float32)
+            line["cpu_baseline"] = cpu_baseline(caps, taps)
+        print(json.dumps(line))
 
 
 def main():
@@ -846,6 +1028,11 @@ def main():
         raise SystemExit("bench.py needs a GPU (no CPU path)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    # One real stream for everything this process queues: torch's default stream has handle 0, which
+    # sdr_set_stream reads as "the chain's own stream" -- the chains would then run beside torch's copies, event
+    # records and the RCCL collectives (ordered on torch's current stream) instead of in order with them.
+    main_stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(main_stream)
     # SDR_BENCH_DIST=1 under torchrun with ONE rank walks the multi-GPU code (RCCL init, frame gather,
     # barriers, max over ranks) on a one-GPU box
     use_dist = world > 1 or (os.environ.get("SDR_BENCH_DIST") == "1" and "MASTER_ADDR" in os.environ)
@@ -948,9 +1135,19 @@ def main():
     samples_per_step = ncap * N_PER_CAPTURE
     total_samples = samples_per_step * args.steps * world
     value = total_samples / elapsed / 1e6
+    fk = float(np.mean(front_ms)) if front_ms else float("nan")
+    bk = float(np.mean(back_ms)) if back_ms else float("nan")
+    # every rank's mean kernel time (one all_gather of a float per rank): the roofline of the slowest and the
+    # fastest GPU stand next to rank 0's
+    rank_fk = [fk]
+    if use_dist:
+        mine = torch.tensor([fk], dtype=torch.float64, device=dev)
+        allk = torch.zeros(world, dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(allk, mine)
+        rank_fk = [float(v) for v in allk.cpu().numpy()]
+    cpu_caps = cpu_sample(iq) if (rank == 0 and not args.no_cpu_baseline) else None
+    line = None
     if rank == 0:
-        fk = float(np.mean(front_ms)) if front_ms else float("nan")
-        bk = float(np.mean(back_ms)) if back_ms else float("nan")
         achieved = BYTES_PER_SAMPLE * samples_per_step / (fk * 1e-3) / 1e9
         traffic, traffic_src = pmc_traffic("k_frontend<true, false> fc32", "captures_per_gpu=%d" % ncap)
         line = {
@@ -969,11 +1166,13 @@ def main():
                          "bytes_per_launch": BYTES_PER_SAMPLE * samples_per_step},
             "frames_decoded": len(frames) * world, "verified": "all captures decode to the transmitted packets; 3 captures bit-exact vs oracle",
         }
+        per_rank = [BYTES_PER_SAMPLE * samples_per_step / (k * 1e-3) / 1e9 / HBM_PEAK_GBS for k in rank_fk]
+        line["roofline"].update({"frac_min": round(min(per_rank), 4), "frac_max": round(max(per_rank), 4),
+                                 "kernel_ms_per_rank": [round(k, 4) for k in rank_fk]})
+        line["cpu_baseline"] = None
         if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(iq, taps)
-        else:
-            line["cpu_baseline"] = None
-        if world == 1:
+            line["cpu_baseline"] = cpu_baseline(cpu_caps, taps)
+        if world == 1 and not use_dist:
             progress("ook_batch_cu8")
             other = {"ook_batch_cu8": cu8_workload(torch, dev, iq, pkts, taps)}
             del iq
@@ -989,10 +1188,22 @@ def main():
             progress("ook_batch_somfy_berner_mumbi")
             other["ook_batch_somfy_berner_mumbi"] = mixed_emitters_workload(torch, dev, args.no_cpu_baseline)
             line["other_workloads"] = other
-        print(json.dumps(line))
     c.close()
     if use_dist:
+        # every rank: one wideband capture cut into `world` segments (configs[4] on N GPUs)
+        del iq
+        torch.cuda.empty_cache()
+        if rank == 0:
+            progress("wideband_pfb64_segments")
+        seg = pfb_segments_workload(torch, dist, dev, rank, world)
+        if rank == 0:
+            line["other_workloads"] = {"wideband_pfb64_segments": seg}
         dist.destroy_process_group()
+        # the CPU leg runs on rank 0 alone, after the process group is gone: no rank waits inside a collective for it
+        if rank == 0 and not args.no_cpu_baseline and world > 1:
+            line["cpu_baseline"] = cpu_baseline(cpu_caps, taps)
+    if rank == 0:
+        print(json.dumps(line))
 
 
 if __name__ == "__main__":

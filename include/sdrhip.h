@@ -264,6 +264,18 @@ SDR_API int sdr_fetch_demod(sdr_handle* h, float* out, size_t cap, size_t* n);
  * (ref: TS33C/stream_decoder.py:20-32): state[0]=idle(0)/frame(1),
  * state[1]=pending symbol count, state[2]=previousSymbolType, state[3]=chunk_id. */
 SDR_API int sdr_decoder_state(sdr_handle* h, int32_t state[4]);
+/* The decoder object's arrays, read back on demand (the Python mirror's lazy attributes and its INFO / TRACE
+ * output; all three synchronise):
+ *  - sdr_fetch_pending_symbols: `currentSymbols` (ref: TS33C/stream_decoder.py:27,102-107), the widths in
+ *    microseconds (float64) collected for a packet that is not complete yet;
+ *  - sdr_fetch_raw_buffer: `rawBuffer` (ref: :28,44-47), the bytes held back until the buffer spans more than
+ *    reset_limit;
+ *  - sdr_fetch_runs: the run table of `row` from the last call that decoded: n = runs + 1 positions, run k of
+ *    the decoded buffer is [out[k], out[k+1]); `edge_positions` of the reference (ref: :65-67) is out[] + 1
+ *    (it indexes the buffer with the forced edge sample in front).  n = 0 when the last call decoded nothing. */
+SDR_API int sdr_fetch_pending_symbols(sdr_handle* h, double* out, size_t cap, size_t* n);
+SDR_API int sdr_fetch_raw_buffer(sdr_handle* h, int8_t* out, size_t cap, size_t* n);
+SDR_API int sdr_fetch_runs(sdr_handle* h, int row, int32_t* out, size_t cap, size_t* n);
 
 /* ---- timing helper ----------------------------------------------------------
  * HIP events on the stream the kernels run on: sdr_timer_start/stop bracket a

@@ -18,9 +18,11 @@ Pinned by the reference's known-answer vectors (tests/golden/kat.json,
 tests/test_oracle_kat.py): TS33C README pulses/gaps -> packet/fields, the two
 ``docs/*.png`` bit tables, TFA tfrec line, somfy frames, mumbi/berner codes.
 
-Every class records what the reference would ``print`` in ``.prints`` and its
-debug() calls in ``.log`` instead of writing to stdout; decoded packets are
-also appended to ``.frames`` (additive, for comparisons).
+Every class records what the reference would ``print`` in ``.prints``, its
+debug() calls (every one the reference makes, TRACE lines included) in ``.log``
+and the text of both, line by line as the reference's stdout had them, in
+``.stdout`` -- instead of writing to stdout; decoded packets are also appended
+to ``.frames`` (additive, for comparisons).
 """
 import math
 from struct import unpack
@@ -47,14 +49,36 @@ class _StreamFrontEnd(object):
         self.previousSymbolType = 0
         self.prints = []
         self.log = []
+        self.stdout = []      # every line the reference would have written, debug output and prints, in order
         self.frames = []
 
-    def debug(self, message, level=0):
+    def debug(self, message, level=0, int_hex=False):
+        """records (level, message) -- and the text Python 2 `print message` wrote for it: str of a string, str of
+        a tuple (= repr of its items) under the array print format of the numpy of the reference's time
+        (legacy='1.13'); int_hex: between np.set_printoptions(formatter={'int': hex}) and its reset
+        (TS33C/stream_decoder.py:168-175)."""
         if self.debug_level >= level:
             self.log.append((level, message))
+            opts = {"legacy": "1.13"}
+            if int_hex:
+                opts["formatter"] = {"int": hex}
+            with np.printoptions(**opts):
+                self.stdout.append(str(message))
 
     def _print(self, text):
         self.prints.append(text)
+        self.stdout.append(text)
+
+    @staticmethod
+    def _array_like_numpy1(pieces):
+        """np.array(list of arrays) as numpy < 1.24 built it: 2-D when the pieces are equally long, else an
+        object array of arrays (what ("Symbols:", symbols.size, symbols) printed)."""
+        if len(set(p.size for p in pieces)) == 1:
+            return np.array(pieces)
+        a = np.empty(len(pieces), dtype=object)
+        for k, p in enumerate(pieces):
+            a[k] = p
+        return a
 
     @staticmethod
     def _split_like_numpy1(symbols, reset_limit):
@@ -77,24 +101,34 @@ class _StreamFrontEnd(object):
         if self.rawBuffer.size * 1e6 / self.sample_rate > self.reset_limit:
             if (self.rawBuffer.size > 0) and ((np.sum(self.rawBuffer) > 0) or (self.currentSymbols.size > 0)):
                 self.currentSymbolType = self.rawBuffer[0]
+                self.debug(("first raw sample", self.rawBuffer[0]), TRACE)
+                self.debug(("last raw sample", self.rawBuffer[-1]), TRACE)
                 self.rawBuffer = np.insert(self.rawBuffer, 0, [1 - self.rawBuffer[0]])
                 self.rawBuffer = np.append(self.rawBuffer, [1 - self.rawBuffer[-1]])
                 self.chunk_id += 1
+                self.debug(("Chunk", self.chunk_id), TRACE)
 
                 edges = np.insert(np.diff(self.rawBuffer), 0, [0])
                 edge_positions = np.ravel(np.nonzero(edges))
+                self.debug(("edge_positions:", edge_positions), TRACE)
+                self.debug(("edges", edges[np.nonzero(edges)]), TRACE)
 
                 if edge_positions.size > 0:
                     symbols = np.diff(edge_positions) * 1e6 / self.sample_rate
                     pieces, symbols_size, symbols_shape0 = self._split_like_numpy1(symbols, self.reset_limit)
+                    self.debug(("Symbols:", symbols_size, self._array_like_numpy1(pieces)), TRACE)
+                    self.debug(("symbols.shape", symbols_shape0), TRACE)
+                    self.debug(("state", self.state), TRACE)
 
                     if symbols_shape0 > 1:
                         self.state = "frame"
 
                     for symbol_chunk in pieces:
+                        self.debug(("state", self.state), TRACE)
                         if (symbols_size == 1) or self.state == "idle":
                             symbol_chunk = symbol_chunk[1::]
                         if symbol_chunk.size > 0:
+                            self.debug(("symbol_chunk:", symbol_chunk.size, symbol_chunk), TRACE)
                             self.state = "frame"
                             if (self.currentSymbols.size > 0) and (self.previousSymbolType == self.currentSymbolType):
                                 self.currentSymbols[-1] += symbol_chunk[0]
@@ -104,6 +138,7 @@ class _StreamFrontEnd(object):
 
                             if self.currentSymbols[0] > self.reset_limit:
                                 self.currentSymbols = self.currentSymbols[1::]
+                            self.debug(("currentSymbols:", self.currentSymbols.size, self.currentSymbols), TRACE)
 
                             if (self.currentSymbols.size > 1) and (self.currentSymbols[-1] > self.reset_limit):
                                 self._decode_packet()
@@ -143,15 +178,24 @@ class TS33CStreamDecoder(_StreamFrontEnd):
         gap_histogram = np.histogram(gaps[np.where(gaps > 0)], "auto")
         self.pulse_short_limit = pulse_histogram[1][pulse_histogram[1].size // 2]
         self.gap_short_limit = gap_histogram[1][gap_histogram[1].size // 2]
+        self.debug(("Pulses:", pulses.size, pulses), TRACE)
+        self.debug(("Pulse Histogram", pulse_histogram), TRACE)
+        self.debug(("pulse_short_limit", self.pulse_short_limit), TRACE)
+        self.debug(("Gaps:", gaps.size, gaps), TRACE)
+        self.debug(("Gaps Histogram", gap_histogram), TRACE)
+        self.debug(("gap_short_limit", self.gap_short_limit), TRACE)
 
         combined = np.empty(pulses.size + gaps.size, dtype=pulses.dtype)
         combined[0::2] = pulses
         combined[1::2] = gaps
+        self.debug(("combined:", combined.size, combined), TRACE)
 
         rawBits = np.empty(combined.size, dtype=np.uint8)
+        self.debug(("rawBits.size", rawBits.size), TRACE)
         rawBits[0::2] = np.where(combined[0::2] < self.pulse_short_limit, 1, 0)
         rawBits[1::2] = np.where(combined[1::2] < self.gap_short_limit, 255, 0)
         rawBits = rawBits[np.where(rawBits <= 1)]
+        self.debug(("rawBits:", rawBits.size, rawBits), TRACE)
 
         parityMask = np.mod(np.arange(rawBits.size) + 1, 9) == 0
         parityBits = np.extract(parityMask, rawBits) == 1
@@ -162,8 +206,9 @@ class TS33CStreamDecoder(_StreamFrontEnd):
         if (packetBits.size % 8) == 0:
             packet = np.packbits(np.invert(packetBits[::-1]))[::-1]
             frame["packet"] = bytes(bytearray(packet.tolist()))
-            self.debug(("packet:", packet.size, packet), INFO)
+            self.debug(("packet:", packet.size, packet), INFO, int_hex=True)
             packetParity = (np.sum(np.split(np.invert(packetBits[::-1]), np.arange(8, packetBits.size, 8)), axis=1)[::-1] % 2) == 0
+            self.debug(("packetParity:", packetParity.size, packetParity), TRACE, int_hex=True)
             if np.array_equal(packetParity, parityBits):
                 if (packet.size == 10) and (packet[0] == 0x9f):
                     p = [int(b) for b in packet]
@@ -243,14 +288,19 @@ class TFAStreamDecoder(_StreamFrontEnd):
             self.frames.append(frame)
             return
         baudrate = int(1e6 / symbol_length)  # raises on NaN like the reference
-        del baudrate
+        self.debug(("symbol_length:", symbol_length), TRACE)
+        self.debug(("baudrate:", baudrate), TRACE)
         data_start = np.where(self.currentSymbols > symbol_length * 1.5)[0][0]
+        self.debug(("data_start:", data_start), TRACE)
         pulses = self.currentSymbols[data_start:-1:2]
         pulses = np.where(pulses < symbol_length, 0, pulses)
         gaps = self.currentSymbols[data_start + 1:-1:2]
+        self.debug(("Pulses:", pulses.size, pulses), TRACE)
+        self.debug(("Gaps:", gaps.size, gaps), TRACE)
         combined = np.empty(pulses.size + gaps.size, dtype=pulses.dtype)
         combined[0::2] = np.floor(pulses / symbol_length)
         combined[1::2] = np.ceil(gaps / symbol_length)
+        self.debug(("combined:", combined.size, combined), TRACE)
 
         rawBits = np.empty(0, dtype=np.uint8)
         for index, symbol in np.ndenumerate(combined):
@@ -259,13 +309,14 @@ class TFAStreamDecoder(_StreamFrontEnd):
                     rawBits = np.append(rawBits, np.ones(int(symbol), dtype=np.uint8))
                 else:
                     rawBits = np.append(rawBits, np.zeros(int(symbol), dtype=np.uint8))
+        self.debug(("rawBits:", rawBits.size, rawBits), TRACE)
         frame["nbits"] = int(rawBits.size)
         if rawBits.size >= 11 * 8:
             packet = np.packbits(rawBits[:11 * 8][::-1])[::-1]
             frame["packet"] = bytes(bytearray(packet.tolist()))
             p = [int(b) for b in packet]
             if crc8(p[2:10]) == p[10]:
-                self.debug(("packet:", packet.size, packet), INFO)
+                self.debug(("packet:", packet.size, packet), INFO, int_hex=True)
                 self.identifier = "{:02X}".format((p[2] << 8) + p[3])
                 self.temperature = (p[4] & 0x0f) * 10 + ((p[5] >> 4) & 0x0f) * 1 + (p[5] & 0x0f) * 0.1 - 40
                 self.humidity = (p[6] & 0x7f)

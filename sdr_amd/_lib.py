@@ -156,6 +156,7 @@ EXPORTS = [
     "sdr_pfb_create", "sdr_redecode", "sdr_set_input_format", "sdr_history_len", "sdr_seek", "sdr_segment_info_get", "sdr_export_bits",
     "sdr_batch_process_static", "sdr_static_scratch_bytes", "sdr_segment_info_rows", "sdr_batch_process_bits",
     "sdr_redecode_multi", "sdr_fetch_frames_multi", "sdr_set_overlap", "sdr_result_stream", "sdr_overlap_state",
+    "sdr_fetch_pending_symbols", "sdr_fetch_raw_buffer", "sdr_fetch_runs",
 ]
 
 _lib = None
@@ -239,6 +240,12 @@ def load():
     L.sdr_fetch_bits.argtypes = [H, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.sdr_fetch_demod.restype = C.c_int
     L.sdr_fetch_demod.argtypes = [H, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.sdr_fetch_pending_symbols.restype = C.c_int
+    L.sdr_fetch_pending_symbols.argtypes = [H, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.sdr_fetch_raw_buffer.restype = C.c_int
+    L.sdr_fetch_raw_buffer.argtypes = [H, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.sdr_fetch_runs.restype = C.c_int
+    L.sdr_fetch_runs.argtypes = [H, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.sdr_decoder_state.restype = C.c_int
     L.sdr_decoder_state.argtypes = [H, C.POINTER(C.c_int32 * 4)]
     for name in ("sdr_timer_start", "sdr_timer_stop"):

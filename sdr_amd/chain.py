@@ -340,6 +340,26 @@ class Chain(object):
         _lib.check(self._h, self._L.sdr_decoder_state(self._h, C.byref(st)))
         return list(st)
 
+    def _fetch_array(self, fn, dtype, *lead):
+        n = C.c_size_t()
+        _lib.check(self._h, fn(self._h, *lead, None, 0, C.byref(n)))
+        out = np.zeros(n.value, dtype)
+        if n.value:
+            _lib.check(self._h, fn(self._h, *lead, C.c_void_p(out.ctypes.data), out.size, C.byref(n)))
+        return out
+
+    def fetch_pending_symbols(self):
+        """`currentSymbols` of the decoder object: float64 widths in microseconds (TS33C/stream_decoder.py:27,102)"""
+        return self._fetch_array(self._L.sdr_fetch_pending_symbols, np.float64)
+
+    def fetch_raw_buffer(self):
+        """`rawBuffer` of the decoder object: the bytes held back so far (TS33C/stream_decoder.py:28,44-47)"""
+        return self._fetch_array(self._L.sdr_fetch_raw_buffer, np.int8)
+
+    def fetch_runs(self, row=0):
+        """run table of the last decoding call: runs + 1 positions (empty if it decoded nothing)"""
+        return self._fetch_array(self._L.sdr_fetch_runs, np.int32, int(row))
+
     def profile_enable(self, on=True):
         _lib.check(self._h, self._L.sdr_profile_enable(self._h, int(on)))
 

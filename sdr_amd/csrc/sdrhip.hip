@@ -169,6 +169,15 @@ static int fail(sdr_handle* h, int code, const std::string& msg)
 // ------------------------------------------------------------------ overlapped batches
 // Entry points that read or replace what a back end writes call ov_join first: h->stream waits for the last
 // event of the result stream, after which the handle behaves as if it had one stream.
+// one wave busy for `cycles` shader clocks (bounded by the clock: every wave ends); sdr_set_overlap's queue probe
+__global__ void k_probe_spin(long long cycles, int* sink)
+{
+    const long long t0 = clock64();
+    while (clock64() - t0 < cycles) {
+    }
+    if (sink && threadIdx.x == 0) *sink = 0;
+}
+
 // SDR_OV_TRACE=1 (diagnostics, read once): every cross-stream record / wait of the overlap pattern on stderr
 static bool ov_trace()
 {
@@ -916,13 +925,33 @@ extern "C" int sdr_set_overlap(sdr_handle* h, int on)
     if (on && !h->bstream) {
         const size_t B = (size_t)h->cfg.max_batch;
         {
-            // A priority of its own, the highest: the back end is a chain of small latency-bound launches that
-            // should not queue behind the front end's workgroups -- and HIP keeps one pool of hardware queues per
-            // priority, so this stream never lands on the hardware queue of h->stream (two streams of the default
-            // priority can; measured: overlapped steps then ran 10 % slower than on one stream).
-            int least = 0, greatest = 0;
-            HIPCHK(h, hipDeviceGetStreamPriorityRange(&least, &greatest));
-            HIPCHK(h, hipStreamCreateWithPriority(&h->bstream, hipStreamNonBlocking, greatest));
+            // The result stream has the SAME priority as the handle's stream.  Round 2 created it at the highest
+            // priority (a hardware queue of its own, never the one h->stream sits on); round 3 found that on this
+            // platform a high-priority stream deadlocks the process once HIP's GPU_MAX_HW_QUEUES (4) normal-priority
+            // hardware queues are all open: the fifth, high-priority queue sits in its barrier packet waiting for an
+            // event of a normal-priority queue that is then never scheduled (tools/probe/two_queue_pmc.hip shows it
+            // without any library code; the same wait pattern at one priority runs).  At one priority HIP hands its
+            // hardware queues out in turn, so a new stream may land on the queue h->stream uses -- correct (one queue
+            // is in submission order) but nothing overlaps.  So candidates are probed: a candidate whose tiny kernel
+            // finishes while a ~2 ms one-wave spin kernel still occupies h->stream's queue sits on another queue.
+            hipStream_t rejected[4];
+            int nrej = 0;
+            int* const flag = nullptr;   // the probe kernels write nothing
+            for (int attempt = 0; attempt < 4 && !h->bstream; ++attempt) {
+                hipStream_t cand = nullptr;
+                HIPCHK(h, hipStreamCreateWithFlags(&cand, hipStreamNonBlocking));
+                hipLaunchKernelGGL(k_probe_spin, dim3(1), dim3(64), 0, h->stream, 5000000LL, flag);
+                hipLaunchKernelGGL(k_probe_spin, dim3(1), dim3(64), 0, cand, 0LL, flag);
+                HIPCHK(h, hipStreamSynchronize(cand));
+                const bool apart = hipStreamQuery(h->stream) == hipErrorNotReady;
+                (void)hipGetLastError();
+                HIPCHK(h, hipStreamSynchronize(h->stream));
+                if (apart || attempt == 3)
+                    h->bstream = cand;
+                else
+                    rejected[nrej++] = cand;   // kept alive until the choice is made: a destroyed stream's queue would be handed out again
+            }
+            for (int i = 0; i < nrej; ++i) (void)hipStreamDestroy(rejected[i]);
         }
         HIPCHK(h, hipEventCreateWithFlags(&h->ov_front, hipEventDisableTiming));
         for (int i = 0; i < 2; ++i) HIPCHK(h, hipEventCreateWithFlags(&h->ov_back[i], hipEventDisableTiming));
@@ -1785,6 +1814,55 @@ extern "C" int sdr_decoder_state(sdr_handle* h, int32_t state[4])
     state[1] = s.n_cur;
     state[2] = s.prev_type;
     state[3] = s.chunk_id;
+    return SDR_OK;
+}
+
+// ---- the decoder object's buffers, for the Python mirror's lazy attributes and its INFO/TRACE output --------
+// ref: TS33C/stream_decoder.py:27-28 (currentSymbols, rawBuffer), :65-74 (edge_positions)
+extern "C" int sdr_fetch_runs(sdr_handle* h, int row, int32_t* outp, size_t cap, size_t* n)
+{
+    if (!h || !n || row < 0) return fail(h, SDR_E_ARG, "sdr_fetch_runs: bad argument");
+    (void)hipSetDevice(h->device);
+    OV_JOIN(h);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    *n = 0;
+    if (!h->runs_valid || row >= h->last_ncap) return SDR_OK;   // the last call only filled the rawBuffer (or had no decoder)
+    int32_t rn = 0;
+    HIPCHK(h, hipMemcpy(&rn, h->d_runs_n + row, sizeof rn, hipMemcpyDeviceToHost));
+    const size_t R = (size_t)((unsigned)rn & 0x7fffffffu);
+    if (R == 0) return SDR_OK;
+    *n = R + 1;   // R run starts + the end of the buffer
+    if (!outp || cap < R + 1) return SDR_OK;
+    HIPCHK(h, hipMemcpy(outp, h->d_runs + (size_t)row * (size_t)(h->runs_cap + 2), (R + 1) * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if ((unsigned)rn >> 31) return fail(h, SDR_E_OVERFLOW, "sdr_fetch_runs: the run table overflowed");
+    return SDR_OK;
+}
+
+extern "C" int sdr_fetch_pending_symbols(sdr_handle* h, double* outp, size_t cap, size_t* n)
+{
+    if (!h || !n) return fail(h, SDR_E_ARG, "sdr_fetch_pending_symbols: bad argument");
+    (void)hipSetDevice(h->device);
+    OV_JOIN(h);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    DecState s;
+    HIPCHK(h, hipMemcpy(&s, h->d_st, sizeof s, hipMemcpyDeviceToHost));
+    const size_t k = s.n_cur > 0 ? (size_t)(s.n_cur < SDR_CUR_CAP ? s.n_cur : SDR_CUR_CAP) : 0;
+    *n = k;
+    if (!outp || cap < k || k == 0) return SDR_OK;
+    HIPCHK(h, hipMemcpy(outp, h->d_cur, k * sizeof(double), hipMemcpyDeviceToHost));
+    return SDR_OK;
+}
+
+extern "C" int sdr_fetch_raw_buffer(sdr_handle* h, int8_t* outp, size_t cap, size_t* n)
+{
+    if (!h || !n) return fail(h, SDR_E_ARG, "sdr_fetch_raw_buffer: bad argument");
+    (void)hipSetDevice(h->device);
+    OV_JOIN(h);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const size_t k = h->raw_n > 0 ? (size_t)h->raw_n : 0;
+    *n = k;
+    if (!outp || cap < k || k == 0) return SDR_OK;
+    HIPCHK(h, hipMemcpy(outp, h->d_bits, k, hipMemcpyDeviceToHost));
     return SDR_OK;
 }
 

@@ -18,13 +18,30 @@ def _env(**kw):
 
 def test_launcher_starts_two_gloo_ranks():
     p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "3", "--warmup", "1"],
-                       env=_env(SDR_BENCH_REHEARSAL="gloo"), capture_output=True, text=True, timeout=300)
+                       env=_env(SDR_BENCH_REHEARSAL="gloo", SDR_BENCH_CPU_BUDGET="0.4"), capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, p.stdout
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["steps"] == 3 and line["warmup"] == 1
     assert line["value"] is None and "rehearsal" in line   # nothing measured, and the line says so
+    # the N > 1 line carries what the N = 1 line does: the CPU leg (rank 0, after the process group is gone, one
+    # core and all cores) and every rank's kernel time
+    cb = line["cpu_baseline"]
+    assert cb is not None and cb["value"] > 0 and cb["cores"] == 1 and cb["all_cores"]["cores"] >= 1
+    assert len(line["roofline"]["kernel_ms_per_rank"]) == 2
+
+
+def test_cpu_workers_do_not_inherit_a_profiler(monkeypatch):
+    sys.path.insert(0, ROOT)
+    import importlib
+    bench = importlib.import_module("bench")
+    monkeypatch.setenv("LD_PRELOAD", "/x/libharness.so:/opt/rocm/lib/rocprofiler-sdk/librocprofiler-sdk-tool.so")
+    monkeypatch.setenv("ROCPROF_COUNTER_COLLECTION", "1")
+    monkeypatch.setenv("ROCP_TOOL_LIBRARIES", "/opt/rocm/lib/librocprofiler-sdk-tool.so")
+    env = bench.worker_env()
+    assert env["LD_PRELOAD"] == "/x/libharness.so"
+    assert not [k for k in env if k.startswith("ROCP")] and env["OMP_NUM_THREADS"] == "1"
 
 
 def test_launcher_refuses_more_gpus_than_present():

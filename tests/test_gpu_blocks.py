@@ -185,3 +185,81 @@ def test_somfy_preamble_blk_gradient_error_and_large_chunk(capsys):
         assert (b.state, b.preamble, b.position) == (o.state, o.preamble, o.position)
     capsys.readouterr()
     b.close()
+
+
+@pytest.mark.parametrize("level", [3, 2])
+def test_ts33c_main_with_trace_prints_the_reference_stdout(kat, capsys, level):
+    """TS33C/stream_decoder.py:222-235 main() as the reference runs it -- StreamDecoder(debug_level=TRACE), the
+    recording cut into 100 chunks -- on the README vector: every line the drop-in writes (the TRACE tuples "first raw
+    sample", "edge_positions:", "Symbols:", "currentSymbols:", the histograms, "Waiting for more data", "skipping
+    empty chunk", "filling rawBuffer", the packet in hex, the result prints) equals what the oracle's statement of
+    the reference writes, rendered the way Python 2 `print` renders a tuple.  Also at INFO (= 2)."""
+    from sdr_amd import ts33c
+    raw = np.concatenate([_readme_bits(kat)] * 3)
+    decoder = ts33c.StreamDecoder(sample_rate=250000, debug_level=level)
+    o = odec.TS33CStreamDecoder(sample_rate=250000, debug_level=level)
+    for chunk in np.array_split(raw, 100):
+        decoder.work([chunk])
+        o.work([chunk])
+    out = capsys.readouterr().out.splitlines()
+    want = "\n".join(o.stdout).splitlines()     # array reprs span lines
+    assert len(want) > (300 if level == 3 else 20)
+    assert out == want
+    if level == 3:
+        assert any(l.startswith("('edge_positions:', array([") for l in out) and "filling rawBuffer" in out
+        assert any(l.startswith("('packet:', 10, array([0x9f, 0x21") for l in out)
+    assert "skipping empty chunk" in out and "Temperature: 21.6°C" in out
+    decoder.close()
+
+
+def test_tfa_main_with_trace_prints_the_reference_stdout(kat, capsys):
+    """TFA/stream_decoder.py:220-234 main(): StreamDecoder(sample_rate=2000000, debug_level=TRACE), 200 chunks."""
+    from sdr_amd import tfa
+    pkt = bytes.fromhex(kat["tfa_readme"]["packet_hex"])
+    sym = synth.tfa_symbols(synth.tfa_bits(pkt), reset_gap_us=4000.0)
+    raw = np.concatenate([synth.envelope(sym, 2e6, lead_in_us=900.0), np.zeros(2000, np.uint8)]).astype(np.int8)
+    raw = np.concatenate([raw, raw])
+    decoder = tfa.StreamDecoder(sample_rate=2000000, debug_level=tfa.TRACE)
+    o = odec.TFAStreamDecoder(sample_rate=2000000, debug_level=3)
+    for chunk in np.array_split(raw, 200):
+        decoder.work([chunk])
+        o.work([chunk])
+    out = capsys.readouterr().out.splitlines()
+    want = "\n".join(o.stdout).splitlines()
+    assert out == want and len(want) > 100
+    assert any(l.startswith("('symbol_length:', ") for l in out) and out.count("Humidity: 54%") == 2
+    decoder.close()
+
+
+def test_stream_decoder_buffers_are_readable(kat):
+    """`rawBuffer` and `currentSymbols` (TS33C/stream_decoder.py:27-28) read back from the handle on access: equal to
+    the oracle's arrays after every work() call of a ragged chunking."""
+    from sdr_amd import ts33c
+    raw = np.concatenate([_readme_bits(kat)] * 2)
+    decoder = ts33c.StreamDecoder(sample_rate=250000)
+    o = odec.TS33CStreamDecoder(sample_rate=250000)
+    rng = np.random.default_rng(11)
+    cuts = sorted(set([0, raw.size] + [int(v) for v in rng.integers(0, raw.size, 40)] + [100, 300, 350]))
+    seen_raw = seen_cur = 0
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        decoder.work([raw[a:b]])
+        o.work([raw[a:b]])
+        r, c = decoder.rawBuffer, decoder.currentSymbols
+        assert r.dtype == o.rawBuffer.dtype and np.array_equal(r, o.rawBuffer)
+        assert c.dtype == o.currentSymbols.dtype and np.array_equal(c, o.currentSymbols)
+        seen_raw += r.size > 0
+        seen_cur += c.size > 0
+    assert seen_raw >= 2 and seen_cur >= 5
+    assert [f["packet"] for f in decoder.frames] == [f["packet"] for f in o.frames] and len(o.frames) == 2
+    decoder.close()
+
+
+def test_oversized_chunk_warns_instead_of_splitting_silently(kat):
+    from sdr_amd import ts33c
+    decoder = ts33c.StreamDecoder(sample_rate=250000)
+    decoder._MAX_CHUNK = 4096          # instance override for the test; the device buffer is larger
+    raw = _readme_bits(kat)
+    with pytest.warns(RuntimeWarning, match="consecutive work"):
+        decoder.work([raw])
+    assert decoder.temperature == 21.6
+    decoder.close()
