@@ -101,10 +101,14 @@ class _StreamDecoderBase(object):
         raw = self._chain.fetch_raw_buffer()
         return raw.astype(self._raw_dtype) if raw.size else np.empty(0, dtype=np.uint8)
 
-    def debug(self, message, level=0):
-        """Debug output depending on debug level."""
+    def debug(self, message, level=0, int_hex=False):
+        """Debug output depending on debug level.  int_hex: the line sits between the reference's
+        np.set_printoptions(formatter={'int': hex}) and its reset (TS33C/stream_decoder.py:168-175)."""
         if self.debug_level >= level:
-            with np.printoptions(legacy="1.13"):
+            opts = {"legacy": "1.13"}
+            if int_hex:
+                opts["formatter"] = {"int": hex}
+            with np.printoptions(**opts):
                 print(message)
 
     def close(self):
@@ -273,11 +277,10 @@ class TS33CStreamDecoder(_StreamDecoderBase):
             packet = f.packet()
             rec["packet"] = packet
             parr = np.frombuffer(packet, np.uint8)
-            with np.printoptions(formatter={"int": hex}):
-                self.debug(("packet:", parr.size, parr), INFO)
-                if packetBits is not None:
-                    packetParity = (np.sum(np.split(np.invert(packetBits[::-1]), np.arange(8, packetBits.size, 8)), axis=1)[::-1] % 2) == 0
-                    self.debug(("packetParity:", packetParity.size, packetParity), TRACE)
+            self.debug(("packet:", parr.size, parr), INFO, int_hex=True)
+            if packetBits is not None:
+                packetParity = (np.sum(np.split(np.invert(packetBits[::-1]), np.arange(8, packetBits.size, 8)), axis=1)[::-1] % 2) == 0
+                self.debug(("packetParity:", packetParity.size, packetParity), TRACE, int_hex=True)
             if f.status == _lib.FRAME_PARITY:
                 self.debug("Parity check failed", ERROR)
             elif f.status == _lib.FRAME_UNKNOWN_HEADER:
@@ -375,8 +378,7 @@ class TFAStreamDecoder(_StreamDecoderBase):
             else:
                 p = bytearray(packet)
                 parr = np.frombuffer(packet, np.uint8)
-                with np.printoptions(formatter={"int": hex}):
-                    self.debug(("packet:", parr.size, parr), INFO)
+                self.debug(("packet:", parr.size, parr), INFO, int_hex=True)
                 self.identifier = "{:02X}".format((p[2] << 8) + p[3])
                 self.temperature = (p[4] & 0x0f) * 10 + ((p[5] >> 4) & 0x0f) * 1 + (p[5] & 0x0f) * 0.1 - 40
                 self.humidity = (p[6] & 0x7f)

@@ -198,7 +198,7 @@ def test_ts33c_main_with_trace_prints_the_reference_stdout(kat, capsys, level):
     raw = np.concatenate([_readme_bits(kat)] * 3)
     decoder = ts33c.StreamDecoder(sample_rate=250000, debug_level=level)
     o = odec.TS33CStreamDecoder(sample_rate=250000, debug_level=level)
-    for chunk in np.array_split(raw, 100):
+    for chunk in [raw[:100], raw[100:100]] + np.array_split(raw[100:], 100):   # 0.4 ms first: "filling rawBuffer"
         decoder.work([chunk])
         o.work([chunk])
     out = capsys.readouterr().out.splitlines()
