@@ -85,19 +85,58 @@ __device__ __forceinline__ void win_epilogue(const FrontParams& P, const int til
         if (lane == 63) s_edge[wave] = make_float2(acc[R - 1].x, acc[R - 1].y);
         __syncthreads();
         if (lane == 0) pv = wave ? s_edge[wave - 1] : make_float2(0.f, 0.f);
+        if (P.quad_fast && !P.tap) {
+            // Threshold-only form (round 3).  The slicer needs whether gain*fast_atan2f(ti, tr) is above hi, below lo
+            // or between -- the arctangent itself (~41 vector instructions: a division, two dependent table reads,
+            // the octant ladder) cost as much as the 27-tap filter of the TFA chain.  fast_atan2f is within 1.6e-6 rad
+            // of the true angle (tests/test_oracle_dsp.py), so a sample whose direction is further than the guard
+            // band (1e-4 rad) from both threshold directions has its class decided by the SIGN of two cross
+            // products |t| sin(theta - phi) and of ti (the arctangent's own y >= 0 test); the few inside a band --
+            // and anything non-finite or of zero length -- take the full arctangent, whole wave, so that every byte
+            // equals the oracle's.  v[] then carries +inf / -inf / lo as stand-ins for "above hi" / "below lo" / "hold".
+            const bool hi_up = P.q_s_hi >= 0.f, lo_up = P.q_s_lo > 0.f;   // threshold directions in the upper half plane (uniform)
+            bool inband = false;
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            // computed for every lane and output (no exec-masked block per output); outputs that do not
-            // exist have zero accumulators, the ones not emitted are dropped by valid[] below
-            const float2 pr = r ? make_float2(acc[r - 1].x, acc[r - 1].y) : pv;
-            const float tr = __builtin_fmaf(acc[r].x, pr.x, acc[r].y * pr.y);
-            const float ti = __builtin_fmaf(acc[r].y, pr.x, -(acc[r].x * pr.y));
-            const float a = fast_atan2f_dev(s_atan, ti, tr);
-            v[r] = valid[r] ? a : 0.f;
+            for (int r = 0; r < R; ++r) {
+                const float2 pr = r ? make_float2(acc[r - 1].x, acc[r - 1].y) : pv;
+                const float tr = __builtin_fmaf(acc[r].x, pr.x, acc[r].y * pr.y);
+                const float ti = __builtin_fmaf(acc[r].y, pr.x, -(acc[r].x * pr.y));
+                const float ch = __builtin_fmaf(ti, P.q_c_hi, -(tr * P.q_s_hi));
+                const float cl = __builtin_fmaf(ti, P.q_c_lo, -(tr * P.q_s_lo));
+                // |t| sin(guard) <= (|tr| + |ti|) * guard: the band test on the 1-norm is at most sqrt(2) wider
+                const float lim = (__builtin_fabsf(tr) + __builtin_fabsf(ti)) * P.q_band;
+                inband |= !(__builtin_fabsf(ch) > lim) || !(__builtin_fabsf(cl) > lim);   // also NaN / Inf / zero length
+                const bool up = ti >= 0.f;
+                const bool gt_hi = hi_up ? (up && ch > 0.f) : (up || ch > 0.f);
+                const bool lt_lo = lo_up ? (!up || cl < 0.f) : (!up && cl < 0.f);
+                v[r] = gt_hi ? __builtin_inff() : (lt_lo ? -__builtin_inff() : P.lo);
+            }
+            if (__ballot(inband) != 0ull) {   // some lane of this wave has a sample inside a band: the wave's tile the exact way
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const float2 pr = r ? make_float2(acc[r - 1].x, acc[r - 1].y) : pv;
+                    const float tr = __builtin_fmaf(acc[r].x, pr.x, acc[r].y * pr.y);
+                    const float ti = __builtin_fmaf(acc[r].y, pr.x, -(acc[r].x * pr.y));
+                    v[r] = P.gain * fast_atan2f_dev(s_atan, ti, tr);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                // computed for every lane and output (no exec-masked block per output); outputs that do not
+                // exist have zero accumulators, the ones not emitted are dropped by valid[] below
+                const float2 pr = r ? make_float2(acc[r - 1].x, acc[r - 1].y) : pv;
+                const float tr = __builtin_fmaf(acc[r].x, pr.x, acc[r].y * pr.y);
+                const float ti = __builtin_fmaf(acc[r].y, pr.x, -(acc[r].x * pr.y));
+                const float a = fast_atan2f_dev(s_atan, ti, tr);
+                v[r] = P.gain * (valid[r] ? a : 0.f);
+            }
         }
     }
+    if (P.demod == SDR_DEMOD_MAG2) {
 #pragma unroll
-    for (int r = 0; r < R; ++r) v[r] = P.gain * v[r];
+        for (int r = 0; r < R; ++r) v[r] = P.gain * v[r];
+    }
     if (P.tap) {
         float* dst = P.tap + (long long)cap * P.tap_stride;
         if (FULL) {

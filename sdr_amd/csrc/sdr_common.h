@@ -92,6 +92,14 @@ struct FrontParams {
     TileSum* tsum;
     int tiles_per_capture;
     int tile_out;           // demod outputs per tile
+    // Discriminator chains that only slice (no demod tap): threshold_ff needs the CLASS of gain*fast_atan2f(ti, tr)
+    // (> hi, < lo, between), not its value.  phi_hi / phi_lo = the arctangent values at which fl(gain*a) crosses
+    // the thresholds (host: exact float search); a sample whose true angle is further than the guard band from
+    // both is classified by two cross-product sign tests, the others take the full arctangent (frontend_win.h).
+    int quad_fast;          // 1: fields below are valid
+    float q_c_hi, q_s_hi;   // cos, sin of phi_hi
+    float q_c_lo, q_s_lo;   // cos, sin of phi_lo
+    float q_band;           // the guard band in radians (applied to the 1-norm of (tr, ti))
 };
 
 #define SDR_KTAPS 64

@@ -117,6 +117,10 @@ struct sdr_handle {
     int tile_override = 0;
     long long seg_min_row = SDR_SEG_MIN_ROW;   // rows this long take the segment- and piece-parallel back end (env SDR_SEG_MIN)
 
+    // threshold-only discriminator (FrontParams.quad_fast): set up once at create
+    bool quad_fast = false;
+    float q_c_hi = 0, q_s_hi = 0, q_c_lo = 0, q_s_lo = 0, q_band = 0;
+
     // internal modes used by the FM chain (fm_host.h)
     struct TailBatch* tail_defer = nullptr;   // set by the FM object around its calls: history updates are collected, not launched
     bool prerotate = false;   // center_freq applies to the INPUT samples (xlating taps=[1] then FIR)
@@ -602,6 +606,38 @@ static bool pick_mfma(const sdr_handle* h, int& T, size_t& lds)
 static int pfb_upload_taps(sdr_handle* h);
 static int scratch_init(sdr_handle* h);
 
+// Threshold-only discriminator (frontend_win.h): the arctangent values at which fl(gain * a) crosses the
+// thresholds, found by walking floats -- a -> fl(gain*a) is monotone for gain > 0, so "gain*a > hi" is
+// "a >= a_hi" for the smallest float a_hi whose product exceeds hi (and likewise below lo).
+static void quad_fast_setup(sdr_handle* h)
+{
+    h->quad_fast = false;
+    const sdr_chain_cfg& c = h->cfg;
+    if (c.demod != SDR_DEMOD_QUAD || c.post_ntaps > 0 || getenv("SDR_NO_QUADFAST")) return;
+    const float g = c.demod_gain, lo = c.thr_lo, hi = c.thr_hi;
+    if (!(g > 0.0f) || !std::isfinite(g) || !std::isfinite(lo) || !std::isfinite(hi) || !(lo <= hi)) return;
+    auto above = [&](float a) { return g * a > hi; };
+    auto below = [&](float a) { return g * a < lo; };
+    float a_hi = (float)((double)hi / (double)g), a_lo = (float)((double)lo / (double)g);
+    for (int i = 0; i < 64 && above(a_hi); ++i) a_hi = std::nextafterf(a_hi, -INFINITY);   // largest float NOT above ...
+    for (int i = 0; i < 64 && !above(a_hi); ++i) a_hi = std::nextafterf(a_hi, INFINITY);   // ... then the smallest above
+    for (int i = 0; i < 64 && below(a_lo); ++i) a_lo = std::nextafterf(a_lo, INFINITY);
+    for (int i = 0; i < 64 && !below(a_lo); ++i) a_lo = std::nextafterf(a_lo, -INFINITY);
+    if (!above(a_hi) || above(std::nextafterf(a_hi, -INFINITY)) || !below(a_lo) || below(std::nextafterf(a_lo, INFINITY))) return;
+    const double guard = 1e-4, pi = M_PI;
+    // both directions well inside (-pi, pi): beyond it a threshold is never / always met and the plain form is kept
+    if (!(std::fabs((double)a_hi) < pi - 0.01) || !(std::fabs((double)a_lo) < pi - 0.01)) return;
+    h->q_c_hi = (float)std::cos((double)a_hi);
+    h->q_s_hi = (float)std::sin((double)a_hi);
+    h->q_c_lo = (float)std::cos((double)a_lo);
+    h->q_s_lo = (float)std::sin((double)a_lo);
+    // a direction within 1e-6 of the real axis would make the "upper half plane" choice of its side rounding-dependent
+    if (std::fabs(h->q_s_hi) < 1e-6f && a_hi != 0.0f) return;
+    if (std::fabs(h->q_s_lo) < 1e-6f && a_lo != 0.0f) return;
+    h->q_band = (float)guard;
+    h->quad_fast = true;
+}
+
 // ------------------------------------------------------------------ create
 extern "C" int sdr_version(void) { return 101; }
 
@@ -765,6 +801,7 @@ extern "C" int sdr_create(const sdr_chain_cfg* cfg, sdr_handle** out)
         // the record has 4 bytes of alignment padding no field assignment reaches: keep them defined
         HIPCHK(h, memset_done(h->d_frames, 0, (size_t)(B * h->cfg.max_frames) * sizeof(sdr_frame)));
         h->keep_ctr = h->cfg.keep_n;
+        quad_fast_setup(h);
         return scratch_init(h);
     };
     rc = body();
@@ -1150,6 +1187,14 @@ static int launch_front(sdr_handle* h, const float2* x, long long stride, long l
     P.tsum = h->d_tsum;
     P.tiles_per_capture = g.tiles;
     P.tile_out = g.tile_out;
+    if (h->quad_fast && P.do_slice && !P.tap && !to_squelch && P.gain == c.demod_gain) {
+        P.quad_fast = 1;
+        P.q_c_hi = h->q_c_hi;
+        P.q_s_hi = h->q_s_hi;
+        P.q_c_lo = h->q_c_lo;
+        P.q_s_lo = h->q_s_lo;
+        P.q_band = h->q_band;
+    }
     if (to_squelch) {
         P.demod = SDR_DEMOD_NONE;
         P.do_slice = 0;

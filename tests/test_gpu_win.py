@@ -161,3 +161,68 @@ def test_win_xlating_demod_slicer_and_streaming(demod, keep_n):
     c.close()
     assert _same_words(np.concatenate(fl), np.float32(gain) * v)
     np.testing.assert_array_equal(np.concatenate(bi), wb)
+
+
+def _quad_bits_oracle(x, taps, gain, lo, hi, keep_n=1):
+    y = odsp.fir_ccf(x, taps, 1)
+    v = odsp.quad_demod(y, 1.0)
+    return odsp.slice_bits(v, gain, lo, hi, keep_n)[0]
+
+
+@pytest.mark.parametrize("gain,lo,hi", [(2.6526, 0.1, 0.4), (0.7, -0.3, 0.3), (1.0, -1.2, -0.4), (5.0, 0.25, 0.25),
+                                        (0.31, -0.9, 0.95), (1.0, 0.0, 0.0), (3.0, -1e-3, 2e-3)])
+def test_quad_threshold_only_path_equals_full_arctangent(gain, lo, hi):
+    """Round 3: a discriminator chain that only slices (no demod tap) classifies gain*fast_atan2f(ti, tr) against the
+    thresholds by cross-product signs outside a guard band (frontend_win.h) and evaluates the arctangent only inside
+    it.  Sliced bytes must equal the chain that keeps the floats (full arctangent everywhere) and the oracle, on
+    noise (angles uniform: every direction incl. the band gets hit), an FSK-like tone pair, zeros and tiny samples."""
+    from sdr_amd import chain
+    rng = np.random.default_rng(int(1000 * gain) + 7)
+    taps = odsp.low_pass(1.0, 2e6, 500e3, 250e3, odsp.WIN_BLACKMAN)
+    n, ncap = 60000 + 123, 4
+    x = np.zeros((ncap, n), np.complex64)
+    x[0] = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+    f = np.where((np.arange(n) // 52) % 2 == 0, 0.02, -0.02) * (1 + 0.2 * rng.standard_normal(n))
+    x[1] = (0.7 * np.exp(2j * np.pi * np.cumsum(f))).astype(np.complex64) + 0.02 * x[0]
+    x[2, 1000:30000] = x[0, 1000:30000] * np.float32(1e-20)           # zero length and denormal products
+    x[3] = x[0] * np.float32(1e15)
+    x[3, 5000] = np.inf
+    x[3, 9000] = np.nan
+    res = {}
+    for tap in (False, True):
+        with chain.Chain(2e6, decim=1, taps=taps, demod=chain.DEMOD_QUAD, demod_gain=gain, thr=(lo, hi), tap_demod=tap,
+                         max_batch=ncap, max_samples=n) as c:
+            c.batch_process(x)
+            res[tap] = c.fetch_bits().reshape(ncap, -1)
+    np.testing.assert_array_equal(res[False], res[True])
+    for i in range(3):
+        np.testing.assert_array_equal(res[False][i], _quad_bits_oracle(x[i], taps, np.float32(gain), lo, hi))
+    # streaming in ragged chunks == one shot
+    with chain.Chain(2e6, decim=1, taps=taps, demod=chain.DEMOD_QUAD, demod_gain=gain, thr=(lo, hi), max_samples=n) as c:
+        parts = []
+        for a, b in zip([0, 7, 3000, 3001, 40000], [7, 3000, 3001, 40000, n]):
+            c.process_iq(x[1][a:b])
+            parts.append(c.fetch_bits())
+    np.testing.assert_array_equal(np.concatenate(parts), _quad_bits_oracle(x[1], taps, np.float32(gain), lo, hi)[:sum(p.size for p in parts)])
+
+
+def test_quad_threshold_only_path_exactly_at_the_thresholds():
+    """Samples whose arctangent lies ON a threshold and within a few ulp / 1e-7 .. 1e-3 rad of it, both thresholds,
+    both sides, all magnitudes: with y[n-1] = 1 the discriminator's argument is the sample itself.  The 9-tap filter
+    [1, 0, ...] passes the samples through exactly.  Bytes equal the oracle's."""
+    from sdr_amd import chain
+    gain, lo, hi = np.float32(2.6526), 0.1, 0.4
+    taps = np.zeros(9, np.float32)
+    taps[0] = 1.0
+    offs = np.concatenate([[0.0], np.logspace(-9, -2.5, 120), -np.logspace(-9, -2.5, 120)])
+    ang = np.concatenate([hi / float(gain) + offs, lo / float(gain) + offs, -hi / float(gain) + offs, np.pi - np.abs(offs), -np.pi + np.abs(offs)])
+    mags = np.array([1.0, 1e-3, 37.5, 1e-12, 1e12])
+    pts = (mags[:, None] * np.exp(1j * ang[None, :])).reshape(-1)
+    x = np.ones(2 * pts.size + 2, np.complex64)
+    x[1:-1:2] = pts.astype(np.complex64)          # 1, p0, 1, p1, ...: arguments p_k and conj(p_k) alternate
+    want = _quad_bits_oracle(x, taps, gain, lo, hi)
+    with chain.Chain(2e6, decim=1, taps=taps, demod=chain.DEMOD_QUAD, demod_gain=float(gain), thr=(lo, hi), max_samples=x.size) as c:
+        c.batch_process(x[None, :])
+        got = c.fetch_bits()
+    np.testing.assert_array_equal(got, want)
+    assert 0 < want.sum() < want.size
