@@ -121,7 +121,10 @@ __device__ __forceinline__ void slice_tile(bool valid, float v, long long o, lon
 // Everything behind the channel filter for thread t's output o = (ar, ai): demodulator, gain,
 // optional tap, hysteresis scan + slicer.  SYNC_TILE: ysh aliases the LDS tile, so every wave must
 // have finished reading it before the discriminator exchange overwrites it.
-template <bool SYNC_TILE>
+// QD = false: the chain's demodulator is known not to be the discriminator, whose arctangent is then not compiled
+// into the kernel at all (round 3: the hot complex64 kernel ran 3 % slower at decimation 10 after a round-2 change
+// to fast_atan2f_dev -- code it never executes for a mag^2 chain -- moved its identical tap loop in memory).
+template <bool SYNC_TILE, bool QD = true>
 __device__ __forceinline__ void frontend_finish(const FrontParams& P, const int tile, const int cap, const int t,
                                                 const int q, const long long o, const float ar, const float ai,
                                                 float2* ysh, int* sh)
@@ -134,7 +137,7 @@ __device__ __forceinline__ void frontend_finish(const FrontParams& P, const int 
         return;
     } else if (P.demod == SDR_DEMOD_MAG2) {
         v = __builtin_fmaf(ar, ar, ai * ai);
-    } else {
+    } else if (QD) {
         if (SYNC_TILE) __syncthreads();  // every wave has finished reading the tile
         ysh[t] = make_float2(ar, ai);
         __syncthreads();
@@ -158,13 +161,13 @@ __device__ __forceinline__ void frontend_finish(const FrontParams& P, const int 
 // (T-1)*D + ntaps input samples are staged once in LDS (coalesced 8-B loads),
 // then every thread walks its ntaps-window with ds_read_b64 + 2 (4) fmaf.
 // QUAD demod needs y[m-1]: thread t computes y[o0-1+t] and emits for t>=1.
-template <bool USE_LDS, bool CU8>
+template <bool USE_LDS, bool CU8, bool QD = true>
 __device__ __forceinline__ void frontend_tile(const FrontParams& P, const FrontKTaps& KT, const int tile, const int cap,
                                               float2* lds, int* sh, float2* ysh_static, const int staged_lsh = -1)
 {
     float2* const ysh = USE_LDS ? lds : ysh_static;
     const int T = blockDim.x;
-    const int q = (P.demod == SDR_DEMOD_QUAD) ? 1 : 0;
+    const int q = (QD && P.demod == SDR_DEMOD_QUAD) ? 1 : 0;
     const long long o0 = (long long)tile * P.tile_out;
     const long long m_t0 = o0 - q;                       // FIR output index of thread 0
     const float2* __restrict__ x = P.x + (long long)cap * P.stride;
@@ -471,20 +474,20 @@ __device__ __forceinline__ void frontend_tile(const FrontParams& P, const FrontK
         }
     }
 
-    frontend_finish<USE_LDS>(P, tile, cap, t, q, o, ar, ai, ysh, sh);
+    frontend_finish<USE_LDS, QD>(P, tile, cap, t, q, o, ar, ai, ysh, sh);
 }
 
 // CU8 = the input is rtl-sdr bytes (sdr_set_input_format).  Aligned cu8 batches and calls
 // run on k_frontend_pipe below; this instantiation is the general path (unaligned buffers,
 // pre-rotation), staging through guarded per-sample fetches.
-template <bool USE_LDS, bool CU8 = false>
+template <bool USE_LDS, bool CU8 = false, bool QD = true>
 __global__ void __launch_bounds__(256) k_frontend(FrontParams P, FrontKTaps KT)
 {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     __shared__ int sh[12];
     // discriminator history exchange: aliases the (by then consumed) tile when there is one
     __shared__ float2 ysh_static[USE_LDS ? 1 : 256];
-    frontend_tile<USE_LDS, CU8>(P, KT, blockIdx.x, blockIdx.y, reinterpret_cast<float2*>(smem_raw), sh, ysh_static);
+    frontend_tile<USE_LDS, CU8, QD>(P, KT, blockIdx.x, blockIdx.y, reinterpret_cast<float2*>(smem_raw), sh, ysh_static);
 }
 
 // Tap loop of k_frontend_raw8: samples are (I, Q) byte pairs in LDS, converted as they are read.

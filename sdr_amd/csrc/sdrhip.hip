@@ -1233,7 +1233,9 @@ static int launch_front(sdr_handle* h, const float2* x, long long stride, long l
             hipLaunchKernelGGL((k_frontend<true, true>), grid, block, g.lds, h->stream, P, h->ktaps);
         else
             hipLaunchKernelGGL((k_frontend<false, true>), grid, block, 0, h->stream, P, h->ktaps);
-    } else if (g.use_lds)
+    } else if (g.use_lds && P.demod != SDR_DEMOD_QUAD)
+        hipLaunchKernelGGL((k_frontend<true, false, false>), grid, block, g.lds, h->stream, P, h->ktaps);
+    else if (g.use_lds)
         hipLaunchKernelGGL((k_frontend<true, false>), grid, block, g.lds, h->stream, P, h->ktaps);
     else
         hipLaunchKernelGGL((k_frontend<false, false>), grid, block, 0, h->stream, P, h->ktaps);

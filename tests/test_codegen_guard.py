@@ -13,7 +13,8 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KERNELS = {
-    "_Z10k_frontendILb1ELb0EEv11FrontParams10FrontKTaps": "k_frontend<true,false>",
+    "_Z10k_frontendILb1ELb0ELb0EEv11FrontParams10FrontKTaps": "k_frontend<true,false,false>",
+    "_Z10k_frontendILb1ELb0ELb1EEv11FrontParams10FrontKTaps": "k_frontend<true,false,true>",
     "_Z15k_frontend_mfma11FrontParams": "k_frontend_mfma",
     "_Z15k_frontend_raw811FrontParams10FrontKTaps": "k_frontend_raw8",
     "_Z5k_pfbILi8EEv9PfbParams": "k_pfb<8>",
@@ -72,7 +73,7 @@ def test_hot_kernels_use_no_scratch_memory(device_asm):
     measured paths must keep their state in registers: private_segment_fixed_size == 0."""
     hot = ["_Z9k_backend10BackParams", "_Z14k_frontend_winILb0EEv11FrontParams", "_Z14k_frontend_winILb1EEv11FrontParams",
            "_Z15k_frontend_mfma11FrontParams", "_Z14k_fir_fff_mfmaPKfS0_ixxxS0_iiPf", "_Z16k_frontend_mfma211FrontParamsi",
-           "_Z10k_frontendILb1ELb0EEv11FrontParams10FrontKTaps", "_Z15k_frontend_raw811FrontParams10FrontKTaps",
+           "_Z10k_frontendILb1ELb0ELb0EEv11FrontParams10FrontKTaps", "_Z10k_frontendILb1ELb0ELb1EEv11FrontParams10FrontKTaps", "_Z15k_frontend_raw811FrontParams10FrontKTaps",
            "_Z5k_pfbILi8EEv9PfbParams", "_Z10k_runs_seg10BackParams", "_Z15k_decode_pieces10BackParams"]
     for sym in hot:
         i = device_asm.index(".amdhsa_kernel " + sym)
