@@ -433,6 +433,15 @@ SDR_API int sdr_fm_create(const sdr_fm_cfg* cfg, sdr_fm** out);
 SDR_API int sdr_fm_destroy(sdr_fm* h);
 SDR_API int sdr_fm_set_stream(sdr_fm* h, void* hip_stream);
 SDR_API int sdr_fm_reset(sdr_fm* h);
+/* Throughput mode of a streaming FM object (no counterpart in the reference, whose flowgraph runs its blocks as
+ * concurrent threads -- this is that pipelining on one GPU): with on != 0 the back half of every sdr_fm_process
+ * call (wfm_rcv's audio FIR, fm_deemph, the 48/50 resampler: ~2 M floats in a few latency-bound launches) is
+ * queued on a second, library-owned stream of the same priority, so that it runs beside the channel filter of the
+ * NEXT call; the next call's discriminator stage waits for it (it overwrites the floats the audio FIR reads).
+ * Same kernels, same results; sdr_fm_fetch / sdr_fm_reset / sdr_fm_set_stream / sdr_fm_destroy order the object's
+ * stream behind the second one first.  Work of a call may still be in flight on the second stream when
+ * sdr_fm_process returns and when the object's stream is idle: synchronise through sdr_fm_fetch (n-only call). */
+SDR_API int sdr_fm_set_overlap(sdr_fm* h, int on);
 /* iq: n complex64 samples (host or device); n_audio receives the audio sample count. */
 SDR_API int sdr_fm_process(sdr_fm* h, const void* iq, size_t n, int is_device_ptr, size_t* n_audio);
 /* stage outputs of the last call (this call's new items only): 0 resampled complex (pairs), 1 discriminator,

@@ -152,7 +152,7 @@ EXPORTS = [
     "sdr_fetch_squelch_counts", "sdr_preamble_create", "sdr_preamble_destroy", "sdr_preamble_work",
     "sdr_preamble_last_error", "sdr_set_prefilter",
     "sdr_fm_create", "sdr_fm_destroy", "sdr_fm_set_stream", "sdr_fm_process", "sdr_fm_fetch",
-    "sdr_fm_last_error", "sdr_fm_reset",
+    "sdr_fm_last_error", "sdr_fm_reset", "sdr_fm_set_overlap",
     "sdr_pfb_create", "sdr_redecode", "sdr_set_input_format", "sdr_history_len", "sdr_seek", "sdr_segment_info_get", "sdr_export_bits",
     "sdr_batch_process_static", "sdr_static_scratch_bytes", "sdr_segment_info_rows", "sdr_batch_process_bits",
     "sdr_redecode_multi", "sdr_fetch_frames_multi", "sdr_set_overlap", "sdr_result_stream", "sdr_overlap_state",
@@ -295,6 +295,8 @@ def load():
     L.sdr_fm_set_stream.argtypes = [H, C.c_void_p]
     L.sdr_fm_process.restype = C.c_int
     L.sdr_fm_process.argtypes = [H, C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_size_t)]
+    L.sdr_fm_set_overlap.restype = C.c_int
+    L.sdr_fm_set_overlap.argtypes = [H, C.c_int]
     L.sdr_fm_reset.restype = C.c_int
     L.sdr_fm_reset.argtypes = [H]
     L.sdr_fm_fetch.restype = C.c_int

@@ -25,8 +25,30 @@ struct sdr_fm {
     unsigned long long c_in = 0, c_out = 0;   // discriminator floats consumed / audio-FIR outputs emitted
     unsigned long long e_in = 0, e_out = 0;   // de-emphasised floats consumed / audio samples emitted
     FmDeemphState* d_deemph = nullptr;        // two slots, read dsel / write dsel^1
-    TailBatch tails{};                        // the call's four history updates, flushed in one launch at its end
+    TailBatch tails{};                        // the call's history updates of the two channel-filter stages, flushed in one launch
+    TailBatch btails{};                       // ... and of the back half (audio FIR, audio resampler)
+    // sdr_fm_set_overlap: the back half (audio FIR, de-emphasis, audio resampler: ~2 M floats, latency-bound launches
+    // of a few hundred workgroups) of chunk k runs on a second stream beside the channel filter of chunk k+1
+    bool overlap = false;
+    hipStream_t bstream = nullptr;
+    hipEvent_t ev_front = nullptr, ev_back[2] = {nullptr, nullptr};
+    bool back_pending = false;                // bstream holds work the main stream has not been ordered behind
+    // the discriminator stage alternates between two output buffers, so that stage B of call k+1 does not wait for
+    // the audio half of call k (still reading its floats) but only for that of call k-1
+    float* d_tap_alt = nullptr;
+    int bsel = 0;                             // buffer / event the current call uses
+    bool back_rec[2] = {false, false};
 };
+
+// the main stream behind everything the back-half stream holds (fetches, reset, destroy, stream changes)
+static int fm_join(sdr_fm* h)
+{
+    if (h && h->back_pending) {
+        if (hipStreamWaitEvent(h->stream, h->ev_back[h->bsel], 0) != hipSuccess) return SDR_E_HIP;
+        h->back_pending = false;
+    }
+    return SDR_OK;
+}
 
 // last H floats of (hist ++ x[0..n)) -> the other history buffer
 static int fm_hist_update(sdr_fm* h, float** bufs, int& sel, int H, const float* x, long long n);
@@ -58,10 +80,18 @@ extern "C" const char* sdr_fm_last_error(sdr_fm* h) { return h ? h->err.c_str() 
 extern "C" int sdr_fm_destroy(sdr_fm* h)
 {
     if (!h) return SDR_OK;
+    if (h->bstream) {
+        (void)hipStreamSynchronize(h->bstream);
+        if (h->stream) (void)hipStreamSynchronize(h->stream);
+        (void)hipStreamDestroy(h->bstream);
+        if (h->ev_front) (void)hipEventDestroy(h->ev_front);
+        for (hipEvent_t e : h->ev_back)
+            if (e) (void)hipEventDestroy(e);
+    }
     if (h->A) sdr_destroy(h->A);
     if (h->B) sdr_destroy(h->B);
     void* ptrs[] = {h->d_ataps, h->d_rtaps, h->d_a2, h->d_a3, h->d_audio, h->d_chist[0], h->d_chist[1], h->d_ehist[0],
-                    h->d_ehist[1], h->d_deemph};
+                    h->d_ehist[1], h->d_deemph, h->d_tap_alt};
     for (void* p : ptrs)
         if (p) (void)dev_free(p);
     delete h;
@@ -195,9 +225,28 @@ extern "C" int sdr_fm_create(const sdr_fm_cfg* cfg, sdr_fm** out)
     return SDR_OK;
 }
 
+extern "C" int sdr_fm_set_overlap(sdr_fm* h, int on)
+{
+    if (!h) return SDR_E_ARG;
+    (void)hipSetDevice(h->A->device);
+    if (fm_join(h)) return fm_fail(h, SDR_E_HIP, "sdr_fm_set_overlap: hipStreamWaitEvent failed");
+    FMCHK(h, hipStreamSynchronize(h->stream));
+    if (on && !h->bstream) {
+        int r = make_side_stream(h->A, h->stream, &h->bstream);
+        if (r) return fm_fail(h, r, h->A->err);
+        FMCHK(h, hipEventCreateWithFlags(&h->ev_front, hipEventDisableTiming));
+        for (int i = 0; i < 2; ++i) FMCHK(h, hipEventCreateWithFlags(&h->ev_back[i], hipEventDisableTiming));
+        FMCHK(h, dev_alloc((void**)&h->d_tap_alt, (size_t)h->B->cfg.max_batch * (size_t)h->B->tap_stride * sizeof(float)));
+    }
+    h->overlap = on != 0;
+    return SDR_OK;
+}
+
 extern "C" int sdr_fm_set_stream(sdr_fm* h, void* s)
 {
     if (!h) return SDR_E_ARG;
+    if (fm_join(h)) return fm_fail(h, SDR_E_HIP, "sdr_fm_set_stream: hipStreamWaitEvent failed");
+    FMCHK(h, hipStreamSynchronize(h->stream));
     h->stream = s ? (hipStream_t)s : h->A->own_stream;
     sdr_set_stream(h->A, (void*)h->stream);
     sdr_set_stream(h->B, (void*)h->stream);
@@ -209,7 +258,7 @@ static int fm_hist_update(sdr_fm* h, float** bufs, int& sel, int H, const float*
     if (n <= 0 || H <= 0) return SDR_OK;
     float* cur = bufs[sel];
     float* nxt = bufs[sel ^ 1];
-    FMCHK(h, tail_update(h->stream, cur, x, (size_t)H * sizeof(float), (size_t)n * sizeof(float), nxt, &h->tails));
+    FMCHK(h, tail_update(h->stream, cur, x, (size_t)H * sizeof(float), (size_t)n * sizeof(float), nxt, &h->btails));
     sel ^= 1;
     return SDR_OK;
 }
@@ -218,6 +267,7 @@ static int fm_hist_update(sdr_fm* h, float** bufs, int& sel, int H, const float*
 extern "C" int sdr_fm_reset(sdr_fm* h)
 {
     if (!h) return SDR_E_ARG;
+    if (fm_join(h)) return fm_fail(h, SDR_E_HIP, "sdr_fm_reset: hipStreamWaitEvent failed");
     FMCHK(h, hipStreamSynchronize(h->stream));
     int rc = chain_restart(h->A);
     if (rc) return fm_fail(h, rc, h->A->err);
@@ -239,7 +289,7 @@ extern "C" int sdr_fm_reset(sdr_fm* h)
 // sample), the audio FIR's history and decimation phase, the de-emphasis delay line (exact, double), the
 // audio resampler's history and output phase.  The first call after create / sdr_fm_reset is the capture from
 // stream start; any chunking of a stream yields the same audio.
-static int fm_process_body(sdr_fm* h, const void* iq, size_t n, int is_dev, size_t* n_audio);
+static int fm_process_body(sdr_fm* h, const void* iq, size_t n, int is_dev, size_t* n_audio, hipStream_t* bsp);
 extern "C" int sdr_fm_process(sdr_fm* h, const void* iq, size_t n, int is_dev, size_t* n_audio)
 {
     if (!h || (!iq && n)) return fm_fail(h, SDR_E_ARG, "sdr_fm_process: bad argument");
@@ -247,15 +297,26 @@ extern "C" int sdr_fm_process(sdr_fm* h, const void* iq, size_t n, int is_dev, s
     // the blocks' memories (two channel-filter histories, audio FIR, audio resampler) are updated by ONE launch
     // behind the call's last kernel; whatever path the body leaves by, what it collected is flushed
     h->tails.count = 0;
+    h->btails.count = 0;
     h->A->tail_defer = h->B->tail_defer = &h->tails;
-    int rc = fm_process_body(h, iq, n, is_dev, n_audio);
+    (void)hipSetDevice(h->A->device);
+    hipStream_t bs = h->stream;       // the stream the back half of THIS call runs on (fm_process_body switches it)
+    int rc = fm_process_body(h, iq, n, is_dev, n_audio, &bs);
     h->A->tail_defer = h->B->tail_defer = nullptr;
     hipError_t e = tail_flush(h->stream, &h->tails);
+    hipError_t e2 = tail_flush(bs, &h->btails);
+    if (e == hipSuccess) e = e2;
+    if (bs != h->stream) {            // whatever the body queued there is what the next call's stage B (and every reader) waits for
+        hipError_t e3 = hipEventRecord(h->ev_back[h->bsel], bs);
+        h->back_rec[h->bsel] = true;
+        h->back_pending = true;
+        if (e == hipSuccess) e = e3;
+    }
     if (rc == SDR_OK && e != hipSuccess) return fm_fail(h, SDR_E_HIP, std::string("history update: ") + hipGetErrorString(e));
     return rc;
 }
 
-static int fm_process_body(sdr_fm* h, const void* iq, size_t n, int is_dev, size_t* n_audio)
+static int fm_process_body(sdr_fm* h, const void* iq, size_t n, int is_dev, size_t* n_audio, hipStream_t* bsp)
 {
     h->n1 = h->n2 = h->n4 = 0;
     if (n_audio) *n_audio = 0;
@@ -263,8 +324,21 @@ static int fm_process_body(sdr_fm* h, const void* iq, size_t n, int is_dev, size
     if (rc) return fm_fail(h, rc, std::string("stage A: ") + h->A->err);
     h->n1 = h->A->last_nout;
     if (h->n1 == 0) return SDR_OK;
+    if (h->overlap && h->bstream) {
+        // stage B writes the buffer the audio half of the call BEFORE LAST read: wait for that one only
+        std::swap(h->B->d_tap, h->d_tap_alt);
+        h->bsel ^= 1;
+        if (h->back_rec[h->bsel]) FMCHK(h, hipStreamWaitEvent(h->stream, h->ev_back[h->bsel], 0));
+    } else if (fm_join(h))
+        return fm_fail(h, SDR_E_HIP, "hipStreamWaitEvent failed");
     rc = sdr_process_iq(h->B, h->A->d_tap, (size_t)h->n1, 1, nullptr);
     if (rc) return fm_fail(h, rc, std::string("stage B: ") + h->B->err);
+    if (h->overlap && h->bstream) {   // everything below runs behind stage B on the second stream
+        FMCHK(h, hipEventRecord(h->ev_front, h->stream));
+        FMCHK(h, hipStreamWaitEvent(h->bstream, h->ev_front, 0));
+        *bsp = h->bstream;
+    }
+    const hipStream_t bs = *bsp;
     // audio FIR: outputs are emitted once audio_decim discriminator floats are consumed
     const int D = h->cfg.audio_decim;
     const unsigned long long c_end = (h->c_in + (unsigned long long)h->n1) / (unsigned long long)D;
@@ -281,14 +355,14 @@ static int fm_process_body(sdr_fm* h, const void* iq, size_t n, int is_dev, size
         if (nw >= 1) {
             const int TB = 256 * nw;
             hipLaunchKernelGGL(k_fir_fff_mfma, dim3((unsigned)((h->n2 + TB - 1) / TB)), dim3(64 * nw),
-                               fir_mfma_lds_bytes(D, h->n_ataps, nw), h->stream, h->B->d_tap,
+                               fir_mfma_lds_bytes(D, h->n_ataps, nw), bs, h->B->d_tap,
                                h->d_chist[h->csel] + (h->chist_len - hv), hv, h->n1, in0, h->n2, h->d_ataps,
                                h->n_ataps, D, h->d_a2);
         } else {
             const int T = 256;
             size_t lds = ((size_t)(T - 1) * D + h->n_ataps) * sizeof(float);
             int blocks = (int)((h->n2 + T - 1) / T);
-            hipLaunchKernelGGL(k_fir_fff_decim, dim3(blocks), dim3(T), lds, h->stream, h->B->d_tap,
+            hipLaunchKernelGGL(k_fir_fff_decim, dim3(blocks), dim3(T), lds, bs, h->B->d_tap,
                                h->d_chist[h->csel] + (h->chist_len - hv), hv, h->n1, in0, h->n2, h->d_ataps,
                                h->n_ataps, D, h->d_a2);
         }
@@ -306,10 +380,10 @@ static int fm_process_body(sdr_fm* h, const void* iq, size_t n, int is_dev, size
         FmDeemphState* st_out = h->d_deemph + (h->dsel ^ 1);
         if (warm <= 2048) {
             long long chunks = (h->n2 + DEEMPH_CHUNK - 1) / DEEMPH_CHUNK;
-            hipLaunchKernelGGL(k_deemph_warm, dim3((unsigned)((chunks + 255) / 256)), dim3(256), deemph_lds_bytes(warm), h->stream, h->d_a2,
+            hipLaunchKernelGGL(k_deemph_warm, dim3((unsigned)((chunks + 255) / 256)), dim3(256), deemph_lds_bytes(warm), bs, h->d_a2,
                                h->n2, h->b0, h->p1, warm, h->d_a3, st_in, st_out);
         } else
-            hipLaunchKernelGGL(k_deemph, dim3(1), dim3(DEEMPH_THREADS), 0, h->stream, h->d_a2, h->n2, h->b0, h->p1,
+            hipLaunchKernelGGL(k_deemph, dim3(1), dim3(DEEMPH_THREADS), 0, bs, h->d_a2, h->n2, h->b0, h->p1,
                                h->d_a3, st_in, st_out);
         FMCHK(h, hipGetLastError());
         h->dsel ^= 1;
@@ -324,11 +398,11 @@ static int fm_process_body(sdr_fm* h, const void* iq, size_t n, int is_dev, size
         const int hv = h->e_in < (unsigned long long)h->ehist_len ? (int)h->e_in : h->ehist_len;
         const size_t rlds = resample_lds_bytes(h->n_rtaps, h->L, h->M);
         if (rlds <= 48 * 1024)
-            hipLaunchKernelGGL(k_resample_fff_lds, dim3(blocks), dim3(256), rlds, h->stream, h->d_a3,
+            hipLaunchKernelGGL(k_resample_fff_lds, dim3(blocks), dim3(256), rlds, bs, h->d_a3,
                                h->d_ehist[h->esel] + (h->ehist_len - hv), hv, h->n2, (long long)h->e_in, (long long)h->e_out,
                                h->n4, h->d_rtaps, h->n_rtaps, h->L, h->M, h->cfg.volume, h->d_audio);
         else   // a polyphase table that does not fit LDS: every step from global memory
-            hipLaunchKernelGGL(k_resample_fff, dim3(blocks), dim3(256), 0, h->stream, h->d_a3,
+            hipLaunchKernelGGL(k_resample_fff, dim3(blocks), dim3(256), 0, bs, h->d_a3,
                                h->d_ehist[h->esel] + (h->ehist_len - hv), hv, h->n2, (long long)h->e_in, (long long)h->e_out,
                                h->n4, h->d_rtaps, h->n_rtaps, h->L, h->M, h->cfg.volume, h->d_audio);
         FMCHK(h, hipGetLastError());
@@ -354,6 +428,7 @@ extern "C" int sdr_fm_fetch(sdr_fm* h, int stage, float* out, size_t cap, size_t
     case 4: src = h->d_audio; cnt = (size_t)h->n4; break;
     default: return fm_fail(h, SDR_E_ARG, "sdr_fm_fetch: stage 0..4");
     }
+    if (fm_join(h)) return fm_fail(h, SDR_E_HIP, "sdr_fm_fetch: hipStreamWaitEvent failed");
     FMCHK(h, hipStreamSynchronize(h->stream));
     *n = cnt;
     if (!out || cap < cnt || cnt == 0) return SDR_OK;

@@ -193,6 +193,39 @@ static bool ov_trace()
         if (ov_trace()) fprintf(stderr, __VA_ARGS__); \
     } while (0)
 
+// A second stream of the same priority as `main_stream` that sits on ANOTHER hardware queue (sdr_set_overlap,
+// sdr_fm_set_overlap; why not a higher priority and why the probe: see sdr_set_overlap).
+static int fail(sdr_handle* h, int code, const std::string& msg);
+static int make_side_stream(sdr_handle* h, hipStream_t main_stream, hipStream_t* out)
+{
+    hipStream_t rejected[4];
+    int nrej = 0;
+    *out = nullptr;
+    for (int attempt = 0; attempt < 4 && !*out; ++attempt) {
+        hipStream_t cand = nullptr;
+        hipError_t e = hipStreamCreateWithFlags(&cand, hipStreamNonBlocking);
+        if (e != hipSuccess) return fail(h, SDR_E_HIP, std::string("hipStreamCreateWithFlags: ") + hipGetErrorString(e));
+        hipLaunchKernelGGL(k_probe_spin, dim3(1), dim3(64), 0, main_stream, 5000000LL, (int*)nullptr);
+        hipLaunchKernelGGL(k_probe_spin, dim3(1), dim3(64), 0, cand, 0LL, (int*)nullptr);
+        e = hipStreamSynchronize(cand);
+        const bool apart = e == hipSuccess && hipStreamQuery(main_stream) == hipErrorNotReady;
+        (void)hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(main_stream);
+        if (e != hipSuccess) {
+            (void)hipStreamDestroy(cand);
+            for (int i = 0; i < nrej; ++i) (void)hipStreamDestroy(rejected[i]);
+            return fail(h, SDR_E_HIP, std::string("side-stream probe: ") + hipGetErrorString(e));
+        }
+        OV_TRACE("[ov] side-stream candidate %d: %s\n", attempt, apart ? "on another hardware queue" : "shares the main stream's queue");
+        if (apart || attempt == 3)
+            *out = cand;
+        else
+            rejected[nrej++] = cand;   // kept alive until the choice is made: a destroyed stream's queue would be handed out again
+    }
+    for (int i = 0; i < nrej; ++i) (void)hipStreamDestroy(rejected[i]);
+    return SDR_OK;
+}
+
 static int ov_join(sdr_handle* h)
 {
     if (h && h->ov_pending) {
@@ -971,24 +1004,8 @@ extern "C" int sdr_set_overlap(sdr_handle* h, int on)
             // hardware queues out in turn, so a new stream may land on the queue h->stream uses -- correct (one queue
             // is in submission order) but nothing overlaps.  So candidates are probed: a candidate whose tiny kernel
             // finishes while a ~2 ms one-wave spin kernel still occupies h->stream's queue sits on another queue.
-            hipStream_t rejected[4];
-            int nrej = 0;
-            int* const flag = nullptr;   // the probe kernels write nothing
-            for (int attempt = 0; attempt < 4 && !h->bstream; ++attempt) {
-                hipStream_t cand = nullptr;
-                HIPCHK(h, hipStreamCreateWithFlags(&cand, hipStreamNonBlocking));
-                hipLaunchKernelGGL(k_probe_spin, dim3(1), dim3(64), 0, h->stream, 5000000LL, flag);
-                hipLaunchKernelGGL(k_probe_spin, dim3(1), dim3(64), 0, cand, 0LL, flag);
-                HIPCHK(h, hipStreamSynchronize(cand));
-                const bool apart = hipStreamQuery(h->stream) == hipErrorNotReady;
-                (void)hipGetLastError();
-                HIPCHK(h, hipStreamSynchronize(h->stream));
-                if (apart || attempt == 3)
-                    h->bstream = cand;
-                else
-                    rejected[nrej++] = cand;   // kept alive until the choice is made: a destroyed stream's queue would be handed out again
-            }
-            for (int i = 0; i < nrej; ++i) (void)hipStreamDestroy(rejected[i]);
+            int r = make_side_stream(h, h->stream, &h->bstream);
+            if (r) return r;
         }
         HIPCHK(h, hipEventCreateWithFlags(&h->ov_front, hipEventDisableTiming));
         for (int i = 0; i < 2; ++i) HIPCHK(h, hipEventCreateWithFlags(&h->ov_back[i], hipEventDisableTiming));

@@ -54,6 +54,16 @@ class FmRadio(object):
     def set_stream(self, ptr):
         self._check(self._L.sdr_fm_set_stream(self._h, C.c_void_p(ptr)))
 
+    def set_overlap(self, on=True):
+        """sdr_fm_set_overlap: the audio half of each process() call on a second stream beside the next call's
+        channel filter (same results; fetch() waits for both streams)."""
+        self._check(self._L.sdr_fm_set_overlap(self._h, int(bool(on))))
+
+    def synchronize(self):
+        """wait for everything process() has queued (both streams)"""
+        n = C.c_size_t()
+        self._check(self._L.sdr_fm_fetch(self._h, 4, None, 0, C.byref(n)))
+
     def reset(self):
         """Back to stream start (every block's state as after construction)."""
         self._check(self._L.sdr_fm_reset(self._h))
