@@ -373,6 +373,50 @@ SDR_API int sdr_segment_info_rows(sdr_handle* h, sdr_segment_info* info, size_t 
  * buffer on the handle's stream, ready for a collective; *n = bytes written. */
 SDR_API int sdr_export_bits(sdr_handle* h, void* bits_dev, size_t cap_bytes, size_t* n);
 
+/* ---- the same capture decoded WITHOUT shipping the sliced bytes (north_star: "RCCL ... used only to gather
+ * decoded frames and counts").  Stream decoders only (TS33C, TFA).  What makes it exact: the reference's front end
+ * (TS33C/stream_decoder.py:76-110 == TFA/stream_decoder.py:96-130) splits the symbol widths behind every width
+ * above reset_limit and decodes each closed piece starting from an empty currentSymbols, so every piece that lies
+ * wholly inside a segment decodes there to what the single stream gives; only the pieces that touch a segment
+ * boundary need the neighbours' runs.
+ *
+ * sdr_segment_decode: call after sdr_seek + ONE sdr_process_iq (the segment) + sdr_segment_info_get, with the
+ * threshold carry-in the exclusive scan over the segments' summaries gave this one (the leading n_undetermined
+ * bytes are rewritten if it differs from what the call assumed).  It decodes the segment's bytes as a stream of
+ * their own (sdr_fetch_frames / sdr_export_frames afterwards; end_pos counts from the segment's first byte) and
+ * returns
+ *   head[0 .. n_head)  the run starts up to and including the END of the first over-limit run,
+ *   tail[0 .. n_tail)  the run starts from the end of the last over-limit run that does not touch the segment's
+ *                      end, up to the segment's length,
+ * both counted from the segment's first byte.  Frames with keep_from < end_pos <= keep_to are the segment's own
+ * (final); the others the local pass produced belong to pieces that the head or the tail carry, and are dropped.
+ * A segment without an over-limit run (or whose only one is its last run) is all head: n_tail = 0.
+ * flags != 0: the head or the tail did not fit the caller's arrays, or a device table overflowed -- fall back to
+ * the byte exchange (sdr_export_bits) for this capture.  Invalidates sdr_segment_info_get for the call.
+ *
+ * sdr_process_runs: ONE work() call of the handle's stream decoder on a stream given by its run starts (host
+ * array, pos[0] = 0 < ... < pos[n_pos - 1] = length) and the levels of its first and last sample, instead of by
+ * its bytes: everything the reference computes behind `edge_positions` (TS33C/stream_decoder.py:63-110) is a
+ * function of those.  The joined heads and tails of all segments (sdr_amd/segments.py: stitch_tables) go here;
+ * frame end positions come back in the table's coordinates. */
+#define SDR_SEG_HEAD_TOO_LONG 1
+#define SDR_SEG_TAIL_TOO_LONG 2
+#define SDR_SEG_TABLE_OVERFLOW 4
+typedef struct sdr_segment_pieces {
+    int64_t n_bits;      /* the segment's sliced bytes */
+    int64_t keep_from;   /* local frames with keep_from < end_pos <= keep_to are final */
+    int64_t keep_to;
+    int32_t n_head, n_tail;
+    int32_t n_runs;      /* runs of the whole segment */
+    int32_t n_frames;    /* frames of the local pass (before the keep window is applied) */
+    int32_t first_level, last_level; /* the segment's first / last sliced byte */
+    int32_t flags;       /* SDR_SEG_* */
+    int32_t pad_;
+} sdr_segment_pieces;
+SDR_API int sdr_segment_decode(sdr_handle* h, int carry_in, int32_t* head, size_t head_cap, int32_t* tail, size_t tail_cap,
+                               sdr_segment_pieces* info);
+SDR_API int sdr_process_runs(sdr_handle* h, const int32_t* pos, size_t n_pos, int first_level, int last_level, sdr_out* out);
+
 /* ---- 64-channel polyphase channelizer (BASELINE.json configs[4]) ----------------
  * The reference has no channelizer block; what this stands for is a bank of 64
  * freq_xlating_fir_filter_ccc(decim 64, taps, center_freq c*fs/64) blocks (the

@@ -123,7 +123,9 @@ class _StreamFrontEnd(object):
                     if symbols_shape0 > 1:
                         self.state = "frame"
 
+                    piece_end = 0   # additive: where each piece ends, for frame["end_pos"]
                     for symbol_chunk in pieces:
+                        piece_end += symbol_chunk.size
                         self.debug(("state", self.state), TRACE)
                         if (symbols_size == 1) or self.state == "idle":
                             symbol_chunk = symbol_chunk[1::]
@@ -141,7 +143,12 @@ class _StreamFrontEnd(object):
                             self.debug(("currentSymbols:", self.currentSymbols.size, self.currentSymbols), TRACE)
 
                             if (self.currentSymbols.size > 1) and (self.currentSymbols[-1] > self.reset_limit):
+                                n_before = len(self.frames)
                                 self._decode_packet()
+                                for f in self.frames[n_before:]:
+                                    # index in this call's rawBuffer (before the two forced samples) behind the
+                                    # over-limit width that closed the packet
+                                    f["end_pos"] = int(edge_positions[piece_end]) - 1
                                 self.currentSymbols = np.empty(0, dtype=np.uint8)
                             else:
                                 self.debug("Waiting for more data", TRACE)

@@ -130,6 +130,22 @@ class PreambleInfo(C.Structure):
     ]
 
 
+class SegmentPieces(C.Structure):
+    _fields_ = [
+        ("n_bits", C.c_int64),
+        ("keep_from", C.c_int64),
+        ("keep_to", C.c_int64),
+        ("n_head", C.c_int32),
+        ("n_tail", C.c_int32),
+        ("n_runs", C.c_int32),
+        ("n_frames", C.c_int32),
+        ("first_level", C.c_int32),
+        ("last_level", C.c_int32),
+        ("flags", C.c_int32),
+        ("pad_", C.c_int32),
+    ]
+
+
 class SegmentInfo(C.Structure):
     _fields_ = [
         ("first_bit_index", C.c_uint64),
@@ -157,6 +173,7 @@ EXPORTS = [
     "sdr_batch_process_static", "sdr_static_scratch_bytes", "sdr_segment_info_rows", "sdr_batch_process_bits",
     "sdr_redecode_multi", "sdr_fetch_frames_multi", "sdr_set_overlap", "sdr_result_stream", "sdr_overlap_state",
     "sdr_fetch_pending_symbols", "sdr_fetch_raw_buffer", "sdr_fetch_runs",
+    "sdr_segment_decode", "sdr_process_runs",
 ]
 
 _lib = None
@@ -280,6 +297,10 @@ def load():
     L.sdr_segment_info_rows.argtypes = [H, C.POINTER(SegmentInfo), C.c_size_t, C.POINTER(C.c_size_t)]
     L.sdr_batch_process_bits.restype = C.c_int
     L.sdr_batch_process_bits.argtypes = [H, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.POINTER(Out)]
+    L.sdr_segment_decode.restype = C.c_int
+    L.sdr_segment_decode.argtypes = [H, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(SegmentPieces)]
+    L.sdr_process_runs.restype = C.c_int
+    L.sdr_process_runs.argtypes = [H, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.POINTER(Out)]
     L.sdr_export_bits.restype = C.c_int
     L.sdr_export_bits.argtypes = [H, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.sdr_batch_process_static.restype = C.c_int

@@ -309,6 +309,28 @@ class Chain(object):
                                                            b.shape[0], 0, C.byref(self.out)))
         return self.out
 
+    def segment_decode(self, carry_in, cap=512):
+        """sdr_segment_decode: decode the segment of the last process_iq call by itself, given the threshold carry-in
+        the scan over the segments' summaries assigned to it.  -> segments.LocalPieces (head / tail run starts
+        counted from the segment's first byte, the keep window for the local frames, levels, flags)."""
+        from . import segments
+        head = np.zeros(cap, np.int32)
+        tail = np.zeros(cap, np.int32)
+        info = _lib.SegmentPieces()
+        _lib.check(self._h, self._L.sdr_segment_decode(self._h, int(carry_in), C.c_void_p(head.ctypes.data), cap,
+                                                       C.c_void_p(tail.ctypes.data), cap, C.byref(info)))
+        return segments.LocalPieces(int(info.n_bits), head[:info.n_head].copy(), tail[:info.n_tail].copy(),
+                                    int(info.first_level), int(info.last_level), int(info.keep_from), int(info.keep_to),
+                                    int(info.flags))
+
+    def process_runs(self, pos, first_level, last_level):
+        """sdr_process_runs: ONE work() call of the stream decoder on a stream given by its run starts
+        (pos[0] = 0 ... pos[-1] = length) and its first / last sample's level; then fetch_frames()."""
+        p = np.ascontiguousarray(pos, np.int32)
+        _lib.check(self._h, self._L.sdr_process_runs(self._h, C.c_void_p(p.ctypes.data), p.size, int(first_level),
+                                                     int(last_level), C.byref(self.out)))
+        return self.out
+
     def export_bits(self, bits_tensor):
         """Last call's sliced bytes into a torch uint8/int8 tensor on this GPU; -> count."""
         n = C.c_size_t()

@@ -268,8 +268,13 @@ __global__ void __launch_bounds__(BK_THREADS, 6) k_backend(BackParams P)
         pos_in_lds = R + 1 <= 2048;
         if (pos_in_lds)
             for (long long k = tid; k <= R; k += BK_THREADS) s_pos[k] = pos[k];
-        first_level = nb > 0 ? (bits[0] != 0) : 0;
-        last_level = nb > 0 ? (bits[nb - 1] != 0) : 0;
+        if (P.lvl_override & 1) {   // the table was handed in without the bytes it describes
+            first_level = (P.lvl_override >> 1) & 1;
+            last_level = (P.lvl_override >> 2) & 1;
+        } else {
+            first_level = nb > 0 ? (bits[0] != 0) : 0;
+            last_level = nb > 0 ? (bits[nb - 1] != 0) : 0;
+        }
         __syncthreads();
     } else if (fast) {
         if (tid == 0) {

@@ -213,4 +213,5 @@ struct BackParams {
     int vrows;
     unsigned int dec_pack;
     RuleState* rule;        // streaming call with a callback-rule decoder: per-row state between calls; nullptr = one call per capture
+    int lvl_override;       // sdr_process_runs (run table without bytes): bit 0 = valid, bit 1 = first sample's level, bit 2 = last sample's
 };

@@ -71,6 +71,7 @@ struct sdr_handle {
     int32_t* d_pieces_hdr = nullptr; // long rows: 8 ints per capture for k_decode_pieces
     bool runs_valid = false;        // ... and whether they describe the current sliced bytes
     bool reuse_next = false;        // set by sdr_redecode around its launch_back
+    int lvl_override = 0;           // set by sdr_process_runs around its launch_back (BackParams.lvl_override)
     long long runs_cap = 0;
     double* d_cur = nullptr;
     DecState* d_st = nullptr;
@@ -1415,6 +1416,7 @@ static int launch_back(sdr_handle* h, int ncap, const CallGeom& g, long long pat
     const bool full_pass = run_decoder && c.decoder != SDR_DEC_NONE && !Bp.nout_var;
     if (h->reuse_next && h->runs_valid && full_pass && !h->no_reuse) {
         Bp.reuse_runs = 1;
+        Bp.lvl_override = h->lvl_override;
         hipLaunchKernelGGL(k_backend, dim3(ncap), dim3(BK_THREADS), 0, bs, Bp);
     } else if (h->d_runs_seg && !Bp.nout_var && run_decoder && c.decoder != SDR_DEC_NONE && nb_total >= h->seg_min_row &&
         !h->no_seg) {
@@ -2228,6 +2230,153 @@ extern "C" int sdr_export_bits(sdr_handle* h, void* bits_dev, size_t cap_bytes, 
                        (size_t)h->bits_stride, width, rows, (unsigned char*)bits_dev);
     HIPCHK(h, hipGetLastError());
     return result_stream_end(h);
+}
+
+// ------------------------------------------------------------------ one long capture, frames-only exchange
+// SURVEY 8e / north_star "RCCL ... used only to gather decoded frames and counts".  The stream decoder
+// (TS33C/stream_decoder.py:76-110) cuts the symbol stream behind every width above reset_limit and decodes each
+// closed piece from an empty currentSymbols, so a rank can decode the pieces that lie wholly inside its segment
+// by itself.  What it cannot decide alone -- the runs up to and including its first over-limit run (the "head")
+// and the runs behind its last over-limit run that does not touch the segment's end (the "tail") -- leaves the
+// rank as two short lists of run-start positions; everything between them collapses into ONE run, which is
+// over-limit by construction and therefore a piece of its own that decodes to nothing.  The reduced tables of all
+// ranks, joined (sdr_amd/segments.py: stitch_tables), go through sdr_process_runs once.
+extern "C" int sdr_segment_decode(sdr_handle* h, int carry_in, int32_t* head, size_t head_cap, int32_t* tail, size_t tail_cap,
+                                  sdr_segment_pieces* info)
+{
+    if (!h || !info || !head || !tail || head_cap < 4 || tail_cap < 4)
+        return fail(h, SDR_E_ARG, "sdr_segment_decode: bad argument");
+    if (!is_stream_decoder(h->cfg.decoder)) return fail(h, SDR_E_ARG, "sdr_segment_decode: needs a stream decoder (TS33C / TFA)");
+    if (h->pfb_M || h->last_ncap != 1 || h->last_bits_off != 0)
+        return fail(h, SDR_E_ARG, "sdr_segment_decode: the segment must be ONE sdr_process_iq call behind sdr_seek");
+    if (carry_in != 0 && carry_in != 1) return fail(h, SDR_E_ARG, "sdr_segment_decode: carry_in must be 0 or 1");
+    (void)hipSetDevice(h->device);
+    OV_JOIN(h);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    memset(info, 0, sizeof *info);
+    const long long nb = h->last_nb;
+    info->n_bits = nb;
+    h->raw_n = 0;   // the segment is consumed here, not buffered for a later call
+    if (nb == 0) return SDR_OK;
+    DecState s;
+    HIPCHK(h, hipMemcpy(&s, h->d_st, sizeof s, hipMemcpyDeviceToHost));
+    // bytes in front of the segment's first threshold event hold the state the stream had when the segment began
+    const long long kn = h->cfg.keep_n, c0 = h->last_keep_c0;
+    long long und = nb;
+    if (s.first_evt >= 0) {
+        und = s.first_evt <= c0 ? 0 : ((long long)s.first_evt - c0 + kn - 1) / kn;
+        if (und > nb) und = nb;
+    }
+    const int assumed = h->carry_last >= 0 ? h->carry_last : h->cfg.thr_init;
+    if (carry_in != assumed && und > 0) HIPCHK(h, hipMemsetAsync(h->d_bits, carry_in, (size_t)und, h->stream));
+    // the segment's bytes as a stream of their own: fresh decoder object, ONE work() call, decoder forced to run
+    CallGeom g;
+    memset(&g, 0, sizeof g);
+    g.ne = nb;
+    g.T = 256;
+    g.tile_out = 256;
+    int r = launch_back(h, 1, g, 0, nb, 1, 0, 1);
+    if (r) return r;
+    OV_JOIN(h);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpy(&s, h->d_st, sizeof s, hipMemcpyDeviceToHost));
+    int32_t rn = 0;
+    HIPCHK(h, hipMemcpy(&rn, h->d_runs_n, sizeof rn, hipMemcpyDeviceToHost));
+    const long long R = (long long)((unsigned)rn & 0x7fffffffu);
+    info->n_runs = (int32_t)R;
+    info->n_frames = s.n_frames;
+    if (((unsigned)rn >> 31) || s.overflow) info->flags |= SDR_SEG_TABLE_OVERFLOW;
+    int8_t lv[2] = {0, 0};
+    HIPCHK(h, hipMemcpy(&lv[0], h->d_bits, 1, hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(&lv[1], h->d_bits + nb - 1, 1, hipMemcpyDeviceToHost));
+    info->first_level = lv[0] != 0;
+    info->last_level = lv[1] != 0;
+    if (R < 1 || (info->flags & SDR_SEG_TABLE_OVERFLOW)) {
+        info->flags |= SDR_SEG_TABLE_OVERFLOW;
+        return SDR_OK;
+    }
+    const double limit = decoder_reset_limit(h->cfg.decoder), rate = h->dec_rate;
+    // head: pos[0 .. i1 + 1], i1 = the first over-limit run
+    const long long nh = R + 1 < (long long)head_cap ? R + 1 : (long long)head_cap;
+    HIPCHK(h, hipMemcpy(head, h->d_runs, (size_t)nh * sizeof(int32_t), hipMemcpyDeviceToHost));
+    long long i1 = -1;
+    for (long long k = 0; k + 1 < nh && i1 < 0; ++k)
+        if (run_width(head, k, rate) > limit) i1 = k;
+    if (i1 < 0 || i1 == R - 1) {
+        // no over-limit run, or only the segment's last one (whose true width the next segment knows): all of it is head
+        if (nh < R + 1) {
+            info->flags |= SDR_SEG_HEAD_TOO_LONG;
+            return SDR_OK;
+        }
+        info->n_head = (int32_t)(R + 1);
+        return SDR_OK;
+    }
+    info->n_head = (int32_t)(i1 + 2);
+    info->keep_from = head[i1 + 1];
+    // tail: pos[j + 1 .. R], j = the last over-limit run in [i1, R - 2]
+    const long long span = R - i1;   // positions pos[i1 + 1 .. R]
+    const long long nt = span < (long long)tail_cap ? span : (long long)tail_cap;
+    HIPCHK(h, hipMemcpy(tail, h->d_runs + (R + 1 - nt), (size_t)nt * sizeof(int32_t), hipMemcpyDeviceToHost));
+    // tail[t] = pos[R + 1 - nt + t]; run k (k >= R + 1 - nt) has its width in tail[k - (R + 1 - nt)] and the entry behind it
+    long long j = -1;
+    for (long long k = R - 2; k >= R + 1 - nt && j < 0; --k)
+        if (run_width(tail, k - (R + 1 - nt), rate) > limit) j = k;
+    if (j < 0) {
+        if (nt < span) {
+            info->flags |= SDR_SEG_TAIL_TOO_LONG;
+            return SDR_OK;
+        }
+        j = i1;   // the window reaches back to the head's separator: nothing lies between head and tail
+    }
+    const long long first = j + 1 - (R + 1 - nt);   // index of pos[j + 1] inside tail[]
+    info->n_tail = (int32_t)(R - j);
+    if (first > 0) memmove(tail, tail + first, (size_t)info->n_tail * sizeof(int32_t));
+    info->keep_to = tail[0];
+    return SDR_OK;
+}
+
+// A sliced stream given as its run starts instead of its bytes: pos[0] = 0 < pos[1] < ... < pos[R] = the stream's
+// length, the first and the last sample's level.  ONE work() call of the handle's stream decoder on it
+// (TS33C/stream_decoder.py:39-110: everything behind line 63 is a function of the edge positions, rawBuffer[0]
+// and rawBuffer[-2] only); frame end positions are positions of this table.
+extern "C" int sdr_process_runs(sdr_handle* h, const int32_t* pos, size_t n_pos, int first_level, int last_level, sdr_out* out)
+{
+    if (!h || !pos || n_pos < 2) return fail(h, SDR_E_ARG, "sdr_process_runs: bad argument");
+    if (!is_stream_decoder(h->cfg.decoder)) return fail(h, SDR_E_ARG, "sdr_process_runs: needs a stream decoder (TS33C / TFA)");
+    if (h->pfb_M || h->raw_n != 0) return fail(h, SDR_E_ARG, "sdr_process_runs: the decoder holds buffered bytes (or is a channelizer)");
+    if (h->no_reuse) return fail(h, SDR_E_ARG, "sdr_process_runs: run-table reuse is switched off (SDR_NO_REUSE)");
+    const long long R = (long long)n_pos - 1;
+    if (R > h->runs_cap) return fail(h, SDR_E_CAPACITY, "sdr_process_runs: more runs than the handle's run table holds");
+    if (pos[0] != 0) return fail(h, SDR_E_ARG, "sdr_process_runs: pos[0] must be 0");
+    for (long long k = 0; k < R; ++k)
+        if (pos[k + 1] <= pos[k]) return fail(h, SDR_E_ARG, "sdr_process_runs: positions must increase");
+    (void)hipSetDevice(h->device);
+    OV_JOIN(h);
+    HIPCHK(h, hipMemcpyAsync(h->d_runs, pos, n_pos * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+    const int32_t rn = (int32_t)R;
+    HIPCHK(h, hipMemcpyAsync(h->d_runs_n, &rn, sizeof rn, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));   // rn lives on this frame
+    const long long total = pos[R];
+    CallGeom g;
+    memset(&g, 0, sizeof g);
+    g.ne = total;
+    g.T = 256;
+    g.tile_out = 256;
+    const int run = ((double)total * 1e6 / h->dec_rate > decoder_reset_limit(h->cfg.decoder)) ? 1 : 0;
+    if (!run) return fail(h, SDR_E_ARG, "sdr_process_runs: shorter than reset_limit (the reference would only buffer it)");
+    h->reuse_next = true;
+    h->runs_valid = true;
+    h->lvl_override = 1 | (first_level ? 2 : 0) | (last_level ? 4 : 0);
+    int r = launch_back(h, 1, g, 0, total, 0, 0, run);
+    h->reuse_next = false;
+    h->runs_valid = false;   // no bytes behind this table: nothing for sdr_redecode to work on
+    h->lvl_override = 0;
+    if (r) return r;
+    h->last_ncap = 1;
+    h->last_nb = 0;
+    h->last_nout = 0;
+    h->last_bits_off = 0;
+    return finish_out(h, out, 0, total);
 }
 
 // ------------------------------------------------------------------ allocation-free batch entry point

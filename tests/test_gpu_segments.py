@@ -180,3 +180,123 @@ def test_seek_argument_checks():
     with chain.Chain(FS, decim=10, taps=_taps(), max_samples=4096, squelch=(-40.0, 1e-4)) as c:
         with pytest.raises(_lib.SdrError):
             c.seek(0)
+
+
+# ---- frames-only exchange (sdr_segment_decode + sdr_process_runs; north_star: RCCL carries frames and counts only)
+def _key(f):
+    return (int(f.end_pos), int(f.status), f.packet(), int(f.nbits), f.lim[0], f.lim[1])
+
+
+def _okey(of):
+    from tests.test_segments_frames import to_frame
+    return _key(to_frame(of))
+
+
+def _long_ts33c_capture(seed, n_pk=7, held=True):
+    """several different packets, a long quiet stretch, and (held) a stretch that sits between the two thresholds
+    entered from a pulse, so that a segment starting inside it is undetermined until the next event"""
+    rng = np.random.default_rng(seed)
+    envs, amps = [], []
+    sym = []
+    for k in range(n_pk):
+        pkt = synth.ts33c_packet(**synth.random_ts33c_fields(rng))
+        sym += synth.ts33c_symbols(synth.ts33c_bits(pkt), rng)
+        if k == 2:
+            sym += [(0, 60000.0)]
+    env = synth.envelope(sym, FS, lead_in_us=4000.0).astype(np.float32)
+    env = np.concatenate([env, np.zeros(5000, np.float32)])
+    iq = synth.ook_iq((env > 0).astype(np.uint8), FS, amp=0.7, sigma=0.02, rng=rng)
+    hold = None
+    if held:
+        # in the quiet stretch behind packet 3: 3 ms of carrier, then 30 ms at |x|^2 = 0.09 (between .05 and .15)
+        edges = np.nonzero(np.diff((env > 0).astype(np.int8)))[0]
+        gaps = np.diff(edges)
+        g = int(np.argmax(gaps))
+        a = int(edges[g]) + 8000
+        iq[a:a + 3000] = 0.7
+        iq[a + 3000:a + 33000] = 0.3
+        hold = (a + 3000, a + 33000)
+    return iq, hold
+
+
+@pytest.mark.parametrize("world,D,keep", [(3, 50, 1), (8, 50, 1), (5, 10, 5), (8, 1, 50)])
+def test_frames_only_exchange_equals_single_pass(world, D, keep):
+    iq, hold = _long_ts33c_capture(world * 7 + D)
+    n = iq.size
+    taps = _taps()
+    want_bits = odsp.ook_chain(iq, taps, D, 1.0, 0.05, 0.15, keep)
+    o = odec.TS33CStreamDecoder(sample_rate=FS / D / keep)
+    o.work([want_bits])
+    want = [_okey(f) for f in o.frames]
+    assert len(want) >= 6
+    al = D * keep
+    bounds = segments.segment_bounds(n, world, al)
+    # one boundary goes inside the held stretch, one into the middle of a packet (the first frame's end - 30 ms)
+    cut_hold = (hold[0] + 9000) // al * al
+    cut_pkt = max(al, (want[0][0] * al - 30000) // al * al)
+    inner = sorted(set([b for _, b in bounds[:-1]][:world - 3] + [cut_hold, cut_pkt]))
+    cuts = [0] + inner + [n]
+    bounds = list(zip(cuts[:-1], cuts[1:]))
+    with chain.Chain(FS, decim=D, taps=taps, keep_n=keep, decoder=chain.DEC_TS33C, max_samples=n, max_frames=32) as c:
+        got, stats = segments.frames_only(c, iq, bounds)
+        assert not stats["fallback"]
+        assert [_key(f) for f in got] == want
+        assert stats["local_frames"] >= 1 and stats["stitched_frames"] >= 2
+        assert stats["table_entries"] * 4 < 64 * 1024
+        # the same handle goes on as a streaming decoder afterwards
+        c.seek(0)
+        c.process_iq(iq)
+        assert [_key(f) for f in c.fetch_frames()] == want
+        # tables that do not fit are flagged, not truncated
+        got2, stats2 = segments.frames_only(c, iq, bounds, cap=8)
+        assert got2 is None and stats2["fallback"]
+
+
+def test_frames_only_exchange_tfa():
+    """TFA analyzer2 shape at 2 Msps (reset_limit 500 us, ~250 widths per packet): segments cut packets in the
+    sync run and in the data; the segment's own pass meets the reference's latent exceptions on the cut packets
+    (status codes here) and the keep window drops them."""
+    fs = 2e6
+    rng = np.random.default_rng(41)
+    sym = []
+    for _ in range(6):
+        pk = synth.tfa_packet(ident=int(rng.integers(0, 65536)), temp_c=float(rng.integers(-300, 500)) / 10.0,
+                              humidity=int(rng.integers(0, 100)))
+        sym += synth.tfa_symbols(synth.tfa_bits(pk), rng, reset_gap_us=float(rng.integers(700, 3000)))
+    env = np.concatenate([synth.envelope(sym, fs, lead_in_us=800.0), np.zeros(2500, np.uint8)])
+    iq = synth.ook_iq(env, fs, amp=0.9, sigma=0.01, rng=rng)
+    n = iq.size
+    want_bits = odsp.ook_chain(iq, np.ones(1, np.float32), 1, 1.0, 0.2, 0.4, 1)
+    o = odec.TFAStreamDecoder(sample_rate=2000000)
+    o.work([want_bits])
+    want = [_okey(f) for f in o.frames]
+    assert len(want) == 6 and all(k[1] == 0 for k in want)
+    for world in (2, 5, 8):
+        inner = sorted(int(v) for v in rng.integers(1, n, world - 1))
+        cuts = [0] + inner + [n]
+        with chain.Chain(fs, decim=1, taps=[1.0], thr=(0.2, 0.4), keep_n=1, decoder=chain.DEC_TFA, max_samples=n,
+                         max_frames=32) as c:
+            got, stats = segments.frames_only(c, iq, list(zip(cuts[:-1], cuts[1:])))
+            assert not stats["fallback"]
+            assert [_key(f) for f in got] == want, cuts
+
+
+def test_process_runs_is_one_work_call():
+    """sdr_process_runs on the run table of a stream == sdr_process_bits on its bytes, state carried over calls"""
+    rng = np.random.default_rng(9)
+    from tests.test_segments_frames import _ts33c_stream
+    bits = _ts33c_stream(rng, 4, held=True)
+    pos = np.concatenate([[0], np.nonzero(np.diff(bits))[0] + 1, [bits.size]]).astype(np.int32)
+    with chain.Chain(20000.0, decoder=chain.DEC_TS33C, max_samples=bits.size, max_frames=16) as a, \
+            chain.Chain(20000.0, decoder=chain.DEC_TS33C, max_samples=bits.size, max_frames=16) as b:
+        for _ in range(2):   # second call: pending symbols and previousSymbolType of the first are in play
+            a.process_bits(bits)
+            b.process_runs(pos, int(bits[0]), int(bits[-1]))
+            fa, fb = a.fetch_frames(), b.fetch_frames()
+            assert len(fa) >= 3 and [_key(f) for f in fa] == [_key(f) for f in fb]
+            assert a.decoder_state() == b.decoder_state()
+            assert np.array_equal(a.fetch_pending_symbols(), b.fetch_pending_symbols())
+        with pytest.raises(_lib_err()):
+            b.process_runs(np.array([0, 5, 5, 9], np.int32), 0, 0)
+        with pytest.raises(_lib_err()):
+            b.process_runs(np.array([0, 9], np.int32), 0, 0)      # shorter than reset_limit
