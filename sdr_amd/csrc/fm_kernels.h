@@ -215,6 +215,26 @@ __global__ void __launch_bounds__(256) k_fir_fff_mfma(const float* __restrict__ 
         } else
             mfma_tail(a, b);
     }
+    // a non-finite input (0 * Inf in the zero-padded products) shows as NaN results: such a wave recomputes its 256
+    // outputs over the taps alone, as k_fir_fff_decim does (see frontend_mfma.h: mfma_exact_redo)
+    {
+        const float s = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+        if (__ballot(!(__builtin_fabsf(s) < __builtin_inff())) != 0ull) {
+            const int G = wave * 16 + (lane & 15);
+            const float* const rt = ldsf + 15 * D;
+#pragma unroll 1
+            for (int r = 0; r < 4; ++r) {
+                const int p0 = BK * G + (4 * (lane >> 4) + r) * D;
+                float a1 = 0.f;
+#pragma unroll 1
+                for (int j = 0; j < ntaps; ++j) {
+                    const int p = p0 + j;
+                    a1 = __builtin_fmaf(rt[j], smp[p + 4 * (p / BK)], a1);
+                }
+                acc[r] = a1;
+            }
+        }
+    }
     // D[row = 4*(lane>>4) + r][col = lane&15] = output 16*col + row of this wave's 256: four consecutive per lane
     const long long o = o0 + wave * 256 + 16 * (lane & 15) + 4 * (lane >> 4);
     if (o + 4 <= nout)

@@ -11,8 +11,13 @@
 // Row i's non-zero terms appear with ascending tap index = oldest sample first,
 // the zero terms are fma(0, x, acc) = acc.  K = 15*D + ntaps, i.e. a fraction
 // ntaps/(15*D+ntaps) of the MFMA work is useful (89 % for 121 taps, D = 1).
-// Limitation: a non-finite input sample (0*Inf) also spoils the <= 15 outputs of
-// its group whose window does not contain it.
+// A non-finite input sample (Inf, NaN) would also spoil the <= 15 outputs of its
+// group whose window does not contain it (0*Inf = NaN in the zero-padded
+// products).  Those come out as NaN, so they are found on the accumulators:
+// a wavefront that holds a non-finite result recomputes its 256 outputs as the
+// plain fmaf chain over the taps alone (mfma_exact_redo) -- what the oracle
+// and the vector kernels do -- and the spoiling stays local to the ntaps
+// outputs whose window holds the sample (round 3; tests/test_gpu_mfma.py).
 //
 // One wavefront = 256 outputs (16 groups x 16); a workgroup of nw <= 4 waves
 // stages (256*nw-1)*D + ntaps samples in LDS.  Group g of a wave reads its
@@ -224,6 +229,37 @@ __device__ __forceinline__ void mfma_kloop(const float* ldsf, const float* smp, 
         mfma_tail(a, b);
 }
 
+// true iff some of the lane's eight results is Inf or NaN (a finite sum that overflows is a harmless false alarm:
+// the redo produces the same values)
+__device__ __forceinline__ bool acc_nonfinite(const f32x4& r, const f32x4& i)
+{
+    const float s = ((r[0] + r[1]) + (r[2] + r[3])) + ((i[0] + i[1]) + (i[2] + i[3]));
+    return !(__builtin_fabsf(s) < __builtin_inff());
+}
+// The wave's 256 outputs once more without the zero-padded products: lane's row 4*(lane>>4) + r of column
+// lane & 15, window = the ntaps samples from position odd + 16*D*G + row*D on (padded image: position p at
+// float 2p + 4*(p / BK)), taps ascending = oldest sample first.  Rare (a capture that holds Inf / NaN): rolled.
+__device__ __forceinline__ void mfma_exact_redo(const float* ldsf, const float* smp, const int D, const int ntaps,
+                                             const int odd, const int lane, const int wave, f32x4& accR, f32x4& accI)
+{
+    const int BK = 16 * D, G = wave * 16 + (lane & 15);
+    const float* const rt = ldsf + 15 * D;
+#pragma unroll 1
+    for (int r = 0; r < 4; ++r) {
+        const int p0 = odd + BK * G + (4 * (lane >> 4) + r) * D;
+        float re = 0.f, im = 0.f;
+#pragma unroll 1
+        for (int j = 0; j < ntaps; ++j) {
+            const int p = p0 + j;
+            const float2 xv = *reinterpret_cast<const float2*>(smp + 2 * p + 4 * (p / BK));
+            re = __builtin_fmaf(rt[j], xv.x, re);
+            im = __builtin_fmaf(rt[j], xv.y, im);
+        }
+        accR[r] = re;
+        accI[r] = im;
+    }
+}
+
 #define MFMA_ROT_K 4   // 16-B loads in flight per lane in the rotating staging loop (8: 145 VGPRs, 3 waves per SIMD)
 // blockDim.x = 64*nw, P.tile_out = 256*nw - q.  Dynamic LDS: tap table | padded samples (aliased by the output tile).
 __global__ void __launch_bounds__(256) k_frontend_mfma(FrontParams P)
@@ -377,6 +413,7 @@ __global__ void __launch_bounds__(256) k_frontend_mfma(FrontParams P)
     // ---- banded Toeplitz product on the f32 matrix cores
     f32x4 accR = {0.f, 0.f, 0.f, 0.f}, accI = {0.f, 0.f, 0.f, 0.f};
     mfma_kloop(ldsf, smp, D, ksteps, odd, lane, wave, accR, accI);
+    if (__ballot(acc_nonfinite(accR, accI)) != 0ull) mfma_exact_redo(ldsf, smp, D, ntaps, odd, lane, wave, accR, accI);
     if (P.demod == SDR_DEMOD_NONE && !P.nco_tab) {
         // complex output with nothing behind the filter (FM chain's resampler stage, squelch input): straight from
         // the accumulators, D[row = 4*(lane>>4) + r][col = lane&15] = four consecutive outputs per lane (32 B) --
@@ -646,6 +683,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))
             } else {
                 f32x4 accR = {0.f, 0.f, 0.f, 0.f}, accI = {0.f, 0.f, 0.f, 0.f};
                 mfma_kloop(ldsf, smp, D, ksteps, odd, lane, wave, accR, accI);
+                if (__ballot(acc_nonfinite(accR, accI)) != 0ull) mfma_exact_redo(ldsf, smp, D, ntaps, odd, lane, wave, accR, accI);
                 // D[row = 4*(lane>>4) + r][col = lane&15]: outputs 16*col + row of this wave's 256 -- four in a row per lane
                 const long long m = (long long)tile * TB + wave * 256 + 16 * (lane & 15) + 4 * (lane >> 4);
                 float2* const o = dst + m;

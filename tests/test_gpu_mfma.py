@@ -164,3 +164,85 @@ def test_mfma_two_team_kernel_batch_stream_and_fallback(D, ntaps, monkeypatch):
         parts.append(c.fetch_demod())
     c.close()
     assert _same_words(np.concatenate(parts), want)
+
+
+def _same_or_both_nan(a, b):
+    """word for word where finite; NaN where NaN (payload and sign of a NaN are not part of the contract); Inf == Inf"""
+    a = np.ascontiguousarray(a).view(np.float32).ravel()
+    b = np.ascontiguousarray(b).view(np.float32).ravel()
+    if a.shape != b.shape:
+        return False
+    nan = np.isnan(a)
+    return np.array_equal(nan, np.isnan(b)) and np.array_equal(a[~nan].view(np.uint32), b[~nan].view(np.uint32))
+
+
+@pytest.mark.parametrize("two_team", [False, True])
+@pytest.mark.parametrize("D,ntaps", [(1, 27), (4, 131), (2, 61)])
+@pytest.mark.parametrize("bad", [np.inf, -np.inf, np.nan])
+def test_mfma_nonfinite_sample_stays_local(D, ntaps, bad, two_team, monkeypatch):
+    """The zero-padded products of the banded-Toeplitz form would turn an Inf / NaN sample into NaN for the <= 15
+    outputs of its 16-output group whose window does not hold it (round-2 limitation).  A wave that ends with a
+    non-finite accumulator recomputes its outputs over the taps alone, so exactly the outputs whose window holds the
+    sample are non-finite -- as in the oracle (one fmaf per tap) and in k_frontend_win -- and every finite word
+    still equals the oracle's.  Both matrix-core front ends, samples at tile / group edges and in the last tile."""
+    from sdr_amd import chain
+    if two_team:
+        monkeypatch.delenv("SDR_NO_MFMA2", raising=False)
+    else:
+        monkeypatch.setenv("SDR_NO_MFMA2", "1")
+    rng = np.random.default_rng(ntaps + D)
+    taps = (rng.standard_normal(ntaps).astype(np.float32) / np.float32(ntaps ** 0.5))
+    taps[taps == 0] = np.float32(0.01)
+    n = 5 * 1024 * D + 333
+    for pos in (0, 7, 16 * D - 1, 16 * D, 1024 * D - 1, 1024 * D, 2 * 1024 * D + 16 * D * 7 + 3, n - ntaps - 2, n - 1):
+        x = _iq(n, 9 + pos % 7, ncap=2) * np.float32(0.3)
+        x[1, pos] = bad
+        c = _chain("mfma", 1e6, decim=D, taps=taps, demod=chain.DEMOD_NONE, tap_demod=True, max_batch=2, max_samples=n)
+        c.batch_process(x)
+        y = c.fetch_demod().reshape(2, -1)
+        c.close()
+        want = odsp.fir_ccf(x[1], taps, D)
+        wbad = ~np.isfinite(want)
+        # outputs m with m*D - (ntaps-1) <= pos <= m*D
+        m_lo, m_hi = -(-pos // D), min(want.size - 1, (pos + ntaps - 1) // D)
+        assert wbad.sum() == max(0, m_hi - m_lo + 1) and (wbad.sum() == 0 or wbad[m_lo:m_hi + 1].all())
+        assert np.array_equal(~np.isfinite(y[1]), wbad), (pos, int((~np.isfinite(y[1])).sum()), int(wbad.sum()))
+        assert _same_or_both_nan(y[1], want)
+        assert _same_words(y[0], odsp.fir_ccf(x[0], taps, D))
+
+
+def test_mfma_nonfinite_through_the_discriminator_chain():
+    """the same through k_frontend_mfma's demod + slicer epilogue: floats and sliced bytes == the oracle chain"""
+    from sdr_amd import chain
+    taps = odsp.low_pass(1.0, 2e6, 20e3, 40e3)      # 121 taps
+    n = 3 * 1024 + 301
+    x = _iq(n, 4, ncap=2) * np.float32(0.5)
+    x[0, 1500] = np.inf
+    x[1, 2000] = np.nan
+    for dm, gain, lo, hi in ((chain.DEMOD_MAG2, 3.0, 0.05, 0.15), (chain.DEMOD_QUAD, 0.7, -0.3, 0.3)):
+        c = _chain("mfma", 1e6, decim=1, taps=taps, demod=dm, demod_gain=gain, thr=(lo, hi), keep_n=1, tap_demod=True,
+                   max_batch=2, max_samples=n)
+        c.batch_process(x)
+        v = c.fetch_demod().reshape(2, -1)
+        b = c.fetch_bits().reshape(2, -1)
+        c.close()
+        for i in range(2):
+            y = odsp.fir_ccf(x[i], taps, 1)
+            wv = odsp.mag2(y) if dm == chain.DEMOD_MAG2 else odsp.quad_demod(y, 1.0)
+            # outputs whose window (or, for the discriminator, whose predecessor's window) holds the sample
+            touched = ~np.isfinite(odsp.mag2(y))
+            touched[1:] |= touched[:-1].copy()
+            assert 100 < touched.sum() < 130
+            assert _same_or_both_nan(v[i][~touched], (np.float32(gain) * wv)[~touched])
+            assert np.isfinite(v[i][~touched]).all()
+            wb, _, _ = odsp.slice_bits(wv, gain, lo, hi, 1)
+            if dm == chain.DEMOD_MAG2:
+                assert _same_or_both_nan(v[i], np.float32(gain) * wv)
+                np.testing.assert_array_equal(b[i], wb)
+            else:
+                # fast_atan2f of a NaN / Inf argument is whatever its comparisons make of it (the oracle's C branches
+                # and the branchless device form need not agree there: parity unpinned, the reference holds no such
+                # sample); the state the slicer is left in behind the stretch may therefore differ, so the bytes are
+                # compared up to the first touched output only
+                first = int(np.argmax(touched))
+                np.testing.assert_array_equal(b[i][:first], wb[:first])
