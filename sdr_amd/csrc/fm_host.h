@@ -12,6 +12,8 @@ struct sdr_fm {
     hipStream_t stream = nullptr;
     std::string err;
     float *d_ataps = nullptr, *d_rtaps = nullptr;  // audio FIR (reversed), resampler taps
+    float* d_rtapsT = nullptr;                // resampler taps as the polyphase table k_deemph_resample reads (row = phase, oldest step first)
+    bool fused_tail = true;                   // SDR_FM_TAIL=split: de-emphasis and resampler as two launches (tuning / test override)
     int n_ataps = 0, n_rtaps = 0, L = 1, M = 1;
     int audio_nw = 4;                         // waves per audio-FIR tile (SDR_FM_AUDIO_NW: tuning)
     bool audio_valu = false;                  // SDR_FM_AUDIO=valu: tuning/test override, read once at create
@@ -90,7 +92,7 @@ extern "C" int sdr_fm_destroy(sdr_fm* h)
     }
     if (h->A) sdr_destroy(h->A);
     if (h->B) sdr_destroy(h->B);
-    void* ptrs[] = {h->d_ataps, h->d_rtaps, h->d_a2, h->d_a3, h->d_audio, h->d_chist[0], h->d_chist[1], h->d_ehist[0],
+    void* ptrs[] = {h->d_rtapsT, h->d_ataps, h->d_rtaps, h->d_a2, h->d_a3, h->d_audio, h->d_chist[0], h->d_chist[1], h->d_ehist[0],
                     h->d_ehist[1], h->d_deemph, h->d_tap_alt};
     for (void* p : ptrs)
         if (p) (void)dev_free(p);
@@ -195,6 +197,18 @@ extern "C" int sdr_fm_create(const sdr_fm_cfg* cfg, sdr_fm** out)
         h->n_rtaps = nt;
         FMCHK(h, dev_alloc((void**)&h->d_rtaps, nt * sizeof(float)));
         FMCHK(h, hipMemcpy(h->d_rtaps, buf.data(), nt * sizeof(float), hipMemcpyHostToDevice));
+        {
+            const int ntq = (nt + h->L - 1) / h->L, ntp = ntq | 1;
+            std::vector<float> tt((size_t)h->L * ntp, 0.0f);
+            for (int p = 0; p < h->L; ++p)
+                for (int j = 0; j < ntq; ++j) {
+                    const int ti = p + (ntq - 1 - j) * h->L;
+                    tt[(size_t)p * ntp + j] = ti < nt ? buf[ti] : 0.0f;
+                }
+            FMCHK(h, dev_alloc((void**)&h->d_rtapsT, tt.size() * sizeof(float)));
+            FMCHK(h, hipMemcpy(h->d_rtapsT, tt.data(), tt.size() * sizeof(float), hipMemcpyHostToDevice));
+            if (const char* e = getenv("SDR_FM_TAIL")) h->fused_tail = strcmp(e, "split") != 0;
+        }
         h->cap2 = n1max / cfg->audio_decim + 2;
         h->cap4 = (h->cap2 * h->L + h->M - 1) / h->M + 2;
         FMCHK(h, dev_alloc((void**)&h->d_a2, (size_t)h->cap2 * sizeof(float)));
@@ -303,6 +317,10 @@ extern "C" int sdr_fm_process(sdr_fm* h, const void* iq, size_t n, int is_dev, s
     hipStream_t bs = h->stream;       // the stream the back half of THIS call runs on (fm_process_body switches it)
     int rc = fm_process_body(h, iq, n, is_dev, n_audio, &bs);
     h->A->tail_defer = h->B->tail_defer = nullptr;
+    if (bs == h->stream) {   // one stream: the four history updates of the call in ONE launch
+        for (int i = 0; i < h->btails.count && h->tails.count < 6; ++i) h->tails.job[h->tails.count++] = h->btails.job[i];
+        h->btails.count = 0;
+    }
     hipError_t e = tail_flush(h->stream, &h->tails);
     hipError_t e2 = tail_flush(bs, &h->btails);
     if (e == hipSuccess) e = e2;
@@ -373,11 +391,27 @@ static int fm_process_body(sdr_fm* h, const void* iq, size_t n, int is_dev, size
     h->c_in += (unsigned long long)h->n1;
     h->c_out = c_end;
     if (h->n2 == 0) return SDR_OK;
-    {
-        // warm-up length after which p1^k < 2^-60; fall back to the scan kernel for poles near 1
-        int warm = (h->p1 > 0.0 && h->p1 < 1.0) ? (int)ceil(-60.0 * log(2.0) / log(h->p1)) : 1 << 30;
-        const FmDeemphState* st_in = h->d_deemph + h->dsel;
-        FmDeemphState* st_out = h->d_deemph + (h->dsel ^ 1);
+    // audio resampler: output m exists once input floor(m*M/L) does
+    const unsigned long long e_in_end = h->e_in + (unsigned long long)h->n2;
+    const unsigned long long e_end = (e_in_end * (unsigned long long)h->L + (unsigned long long)h->M - 1ull) / (unsigned long long)h->M;
+    h->n4 = (long long)(e_end - h->e_out);
+    if (h->n4 > h->cap4) return fm_fail(h, SDR_E_CAPACITY, "sdr_fm_process: audio buffer too small");
+    // warm-up length after which p1^k < 2^-60; fall back to the scan kernel for poles near 1
+    const int warm = (h->p1 > 0.0 && h->p1 < 1.0) ? (int)ceil(-60.0 * log(2.0) / log(h->p1)) : 1 << 30;
+    const FmDeemphState* st_in = h->d_deemph + h->dsel;
+    FmDeemphState* st_out = h->d_deemph + (h->dsel ^ 1);
+    const int ehv = h->e_in < (unsigned long long)h->ehist_len ? (int)h->e_in : h->ehist_len;
+    const int ntq = (h->n_rtaps + h->L - 1) / h->L;
+    if (h->fused_tail && warm <= 2048 && ntq - 1 <= FR_HALO && deemph_resample_lds_bytes(warm, ntq, h->L) <= 64 * 1024) {
+        // both blocks in one launch: the de-emphasised floats reach the resampler through LDS
+        const long long own = FR_RANGE - FR_HALO;
+        hipLaunchKernelGGL(k_deemph_resample, dim3((unsigned)((h->n2 + own - 1) / own)), dim3(256),
+                           deemph_resample_lds_bytes(warm, ntq, h->L), bs, h->d_a2, h->n2, h->b0, h->p1, warm, h->d_a3, st_in,
+                           st_out, h->d_ehist[h->esel] + (h->ehist_len - ehv), ehv, (long long)h->e_in, (long long)h->e_out,
+                           h->n4, h->d_rtapsT, ntq, h->L, h->M, h->cfg.volume, h->d_audio);
+        FMCHK(h, hipGetLastError());
+        h->dsel ^= 1;
+    } else {
         if (warm <= 2048) {
             long long chunks = (h->n2 + DEEMPH_CHUNK - 1) / DEEMPH_CHUNK;
             hipLaunchKernelGGL(k_deemph_warm, dim3((unsigned)((chunks + 255) / 256)), dim3(256), deemph_lds_bytes(warm), bs, h->d_a2,
@@ -387,25 +421,19 @@ static int fm_process_body(sdr_fm* h, const void* iq, size_t n, int is_dev, size
                                h->d_a3, st_in, st_out);
         FMCHK(h, hipGetLastError());
         h->dsel ^= 1;
-    }
-    // audio resampler: output m exists once input floor(m*M/L) does
-    const unsigned long long e_in_end = h->e_in + (unsigned long long)h->n2;
-    const unsigned long long e_end = (e_in_end * (unsigned long long)h->L + (unsigned long long)h->M - 1ull) / (unsigned long long)h->M;
-    h->n4 = (long long)(e_end - h->e_out);
-    if (h->n4 > h->cap4) return fm_fail(h, SDR_E_CAPACITY, "sdr_fm_process: audio buffer too small");
-    if (h->n4 > 0) {
-        int blocks = (int)((h->n4 + 255) / 256);
-        const int hv = h->e_in < (unsigned long long)h->ehist_len ? (int)h->e_in : h->ehist_len;
-        const size_t rlds = resample_lds_bytes(h->n_rtaps, h->L, h->M);
-        if (rlds <= 48 * 1024)
-            hipLaunchKernelGGL(k_resample_fff_lds, dim3(blocks), dim3(256), rlds, bs, h->d_a3,
-                               h->d_ehist[h->esel] + (h->ehist_len - hv), hv, h->n2, (long long)h->e_in, (long long)h->e_out,
-                               h->n4, h->d_rtaps, h->n_rtaps, h->L, h->M, h->cfg.volume, h->d_audio);
-        else   // a polyphase table that does not fit LDS: every step from global memory
-            hipLaunchKernelGGL(k_resample_fff, dim3(blocks), dim3(256), 0, bs, h->d_a3,
-                               h->d_ehist[h->esel] + (h->ehist_len - hv), hv, h->n2, (long long)h->e_in, (long long)h->e_out,
-                               h->n4, h->d_rtaps, h->n_rtaps, h->L, h->M, h->cfg.volume, h->d_audio);
-        FMCHK(h, hipGetLastError());
+        if (h->n4 > 0) {
+            int blocks = (int)((h->n4 + 255) / 256);
+            const size_t rlds = resample_lds_bytes(h->n_rtaps, h->L, h->M);
+            if (rlds <= 48 * 1024)
+                hipLaunchKernelGGL(k_resample_fff_lds, dim3(blocks), dim3(256), rlds, bs, h->d_a3,
+                                   h->d_ehist[h->esel] + (h->ehist_len - ehv), ehv, h->n2, (long long)h->e_in, (long long)h->e_out,
+                                   h->n4, h->d_rtaps, h->n_rtaps, h->L, h->M, h->cfg.volume, h->d_audio);
+            else   // a polyphase table that does not fit LDS: every step from global memory
+                hipLaunchKernelGGL(k_resample_fff, dim3(blocks), dim3(256), 0, bs, h->d_a3,
+                                   h->d_ehist[h->esel] + (h->ehist_len - ehv), ehv, h->n2, (long long)h->e_in, (long long)h->e_out,
+                                   h->n4, h->d_rtaps, h->n_rtaps, h->L, h->M, h->cfg.volume, h->d_audio);
+            FMCHK(h, hipGetLastError());
+        }
     }
     rc = fm_hist_update(h, h->d_ehist, h->esel, h->ehist_len, h->d_a3, h->n2);
     if (rc) return rc;

@@ -464,3 +464,200 @@ __global__ void __launch_bounds__(256) k_resample_fff(const float* __restrict__ 
     }
     out[ml] = volume * a;
 }
+
+// ---- de-emphasis and audio resampler in ONE launch (round 3) ---------------------------------------------------
+// k_deemph_warm + k_resample_fff_lds walked the 1.7 M audio-rate floats twice through HBM with a launch each
+// (0.022 + 0.020 ms of the 0.375 ms step; 410 + 6300 workgroups, the second one filling a 3.4-KB transposed tap
+// table with a division per entry in every workgroup).  Here a workgroup of 256 threads computes FR_RANGE
+// consecutive de-emphasised floats exactly as k_deemph_warm does (thread = 16 outputs, warmed up over `warm` earlier
+// inputs, exact state at stream / call start), the first FR_HALO of which repeat the previous workgroup's last ones
+// (the resampler's history; positions before the call come from `hist`, the resampler block's own memory), leaves its
+// own FR_RANGE - FR_HALO of them in y, and then emits the resampler outputs whose newest input lies in its own span,
+// reading the floats back from LDS.  tapT: the polyphase table already transposed by the host
+// (tapT[p * ntp + j] = h[p + (nt-1-j) L], 0 past the filter; ntp = nt | 1).  Same operations in the same order
+// as the two kernels it replaces.  Dynamic LDS: deemph_resample_lds_bytes(warm, nt, L).
+#define FR_RANGE 4096
+#define FR_HALO 48      // >= taps per phase - 1 (host checks), multiple of DEEMPH_CHUNK
+static inline size_t deemph_resample_lds_bytes(int warm, int nt, int L)
+{
+    const int nst = FR_RANGE + warm + 1;
+    return (size_t)(DEEMPH_PAD(nst) + 1 + DEEMPH_PAD(FR_RANGE) + 1 + L * (nt | 1)) * sizeof(float);
+}
+__global__ void __launch_bounds__(256) k_deemph_resample(const float* __restrict__ x, long long n, double b0, double p1,
+                                                         int warm, float* __restrict__ y,
+                                                         const FmDeemphState* __restrict__ st_in,
+                                                         FmDeemphState* __restrict__ st_out,
+                                                         const float* __restrict__ hist, int hist_len, long long i_base,
+                                                         long long m0, long long nout, const float* __restrict__ tapT_g,
+                                                         int nt, int L, int M, float volume, float* __restrict__ out)
+{
+    extern __shared__ float dl[];
+    constexpr int OWN = FR_RANGE - FR_HALO;
+    const int nst = FR_RANGE + warm + 1, ntp = nt | 1;
+    float* const yo = dl + DEEMPH_PAD(nst) + 1;             // the workgroup's FR_RANGE outputs, padded
+    float* const tapT = yo + DEEMPH_PAD(FR_RANGE) + 1;
+    float* const ys = dl;                                   // ... unpadded, once the inputs are consumed
+    const long long B0 = (long long)blockIdx.x * OWN;       // first position this workgroup owns
+    const long long C0 = B0 - FR_HALO;                      // first position it computes
+    const long long g0 = C0 - warm - 1;                     // sample index of staged position 0
+    if (g0 >= 0 && g0 + nst <= n) {
+        // interior workgroup (uniform): eight unguarded loads in flight per lane before the first LDS store -- a
+        // guarded load -> store per round is a chain of nst / 256 = 17 HBM round trips per workgroup
+        const float* __restrict__ xg = x + g0;
+        for (int j0 = 0; j0 < nst; j0 += 8 * 256) {
+            float r[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int j = j0 + k * 256 + (int)threadIdx.x;
+                r[k] = xg[j < nst ? j : nst - 1];
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int j = j0 + k * 256 + (int)threadIdx.x;
+                if (j < nst) dl[DEEMPH_PAD(j)] = r[k];
+            }
+        }
+    } else {
+        for (int j = threadIdx.x; j < nst; j += 256) {
+            const long long g = g0 + j;
+            dl[DEEMPH_PAD(j)] = (g >= 0 && g < n) ? x[g] : 0.f;
+        }
+    }
+    {
+        const int ntab = L * ntp;
+        for (int j0 = 0; j0 < ntab; j0 += 4 * 256) {
+            float r[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int j = j0 + k * 256 + (int)threadIdx.x;
+                r[k] = tapT_g[j < ntab ? j : ntab - 1];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int j = j0 + k * 256 + (int)threadIdx.x;
+                if (j < ntab) tapT[j] = r[k];
+            }
+        }
+    }
+    __syncthreads();
+    const long long a0 = C0 + (long long)threadIdx.x * DEEMPH_CHUNK;
+    if (a0 + DEEMPH_CHUNK <= 0) {
+        // positions before this call: the resampler's memory (zeros before stream start)
+        int o = threadIdx.x * DEEMPH_CHUNK;
+        for (int k = 0; k < DEEMPH_CHUNK; ++k, ++o) {
+            const long long idx = a0 + k;
+            yo[DEEMPH_PAD(o)] = (hist && idx >= -(long long)hist_len) ? hist[hist_len + idx] : 0.f;
+        }
+    } else if (a0 < n) {
+        const long long a1 = (a0 + DEEMPH_CHUNK < n) ? a0 + DEEMPH_CHUNK : n;
+        long long i = a0 - warm;
+        double yp = 0.0, xp;
+        if (i <= 0) {
+            i = 0;
+            yp = st_in->yp;
+            xp = st_in->xp;
+        } else {
+            const int jp = (int)(i - 1 - g0);
+            xp = (double)dl[DEEMPH_PAD(jp)];
+        }
+        int j = (int)(i - g0);
+        // The recurrence's only serial part is acc += p1 * yp (one multiply, one add).  Eight steps at a time: the
+        // eight inputs are read from LDS together and b0*x[i] + b0*x[i-1] is formed for all of them before the
+        // chain runs -- a step by step loop paid an LDS round trip and five dependent fp64 operations per step
+        // (0.041 ms for 1.7 M floats; the same operations in the same order per sample, so the same bits).
+        for (; i + 8 <= a0; i += 8, j += 8) {
+            double xs8[8], t8[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) xs8[k] = (double)dl[DEEMPH_PAD(j + k)];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                double acc = b0 * xs8[k];
+                acc += b0 * (k ? xs8[k - 1] : xp);
+                t8[k] = acc;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                double acc = t8[k];
+                acc += p1 * yp;
+                yp = acc;
+            }
+            xp = xs8[7];
+        }
+        for (; i < a0; ++i, ++j) {
+            const double xi = (double)dl[DEEMPH_PAD(j)];
+            double acc = b0 * xi;
+            acc += b0 * xp;
+            acc += p1 * yp;
+            xp = xi;
+            yp = acc;
+        }
+        int o = threadIdx.x * DEEMPH_CHUNK;
+        for (; i + 8 <= a1; i += 8, j += 8, o += 8) {
+            double xs8[8], t8[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) xs8[k] = (double)dl[DEEMPH_PAD(j + k)];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                double acc = b0 * xs8[k];
+                acc += b0 * (k ? xs8[k - 1] : xp);
+                t8[k] = acc;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                double acc = t8[k];
+                acc += p1 * yp;
+                yp = acc;
+                yo[DEEMPH_PAD(o + k)] = (float)acc;
+            }
+            xp = xs8[7];
+        }
+        for (; i < a1; ++i, ++j, ++o) {
+            const double xi = (double)dl[DEEMPH_PAD(j)];
+            double acc = b0 * xi;
+            acc += b0 * xp;
+            acc += p1 * yp;
+            xp = xi;
+            yp = acc;
+            yo[DEEMPH_PAD(o)] = (float)acc;
+        }
+        if (a1 == n && a0 >= B0) {   // the owner of the call's last sample (halo threads repeat a neighbour's work)
+            st_out->xp = xp;
+            st_out->yp = yp;
+        }
+    }
+    __syncthreads();
+    // outputs to memory (own part only) and, unpadded, to ys for the resampler
+    for (int j = threadIdx.x; j < FR_RANGE; j += 256) {
+        const float v = (C0 + j < n) ? yo[DEEMPH_PAD(j)] : 0.f;
+        ys[j] = v;
+        if (j >= FR_HALO && C0 + j < n) y[C0 + j] = v;
+    }
+    __syncthreads();
+    // resampler outputs m (absolute) whose newest input floor(m M / L) lies in [i_base + B0, i_base + B1)
+    const long long B1 = (B0 + OWN < n) ? B0 + OWN : n;
+    if (B1 <= B0) return;
+    const long long I0 = i_base + B0, I1 = i_base + B1;
+    const long long m_lo = (I0 * L + M - 1) / M, m_hi = (I1 * L + M - 1) / M;   // uniform
+    long long m = m_lo + threadIdx.x;
+    if (m >= m_hi) return;
+    const long long num = m * (long long)M;
+    long long iq_ = num / L;
+    int p = (int)(num - iq_ * L);
+    const int di = (256 * M) / L, dp = (256 * M) % L;
+    for (; m < m_hi; m += 256) {
+        const int base = (int)(iq_ - i_base - C0) - (nt - 1);   // >= FR_HALO - (nt-1) >= 0
+        const float* tr = tapT + p * ntp;
+        const float* xr = ys + base;
+        float a = 0.f;
+#pragma unroll 8
+        for (int j = 0; j < nt; ++j) a = __builtin_fmaf(tr[j], xr[j], a);   // oldest first
+        const long long ml = m - m0;
+        if (ml >= 0 && ml < nout) out[ml] = volume * a;
+        iq_ += di;
+        p += dp;
+        if (p >= L) {
+            p -= L;
+            ++iq_;
+        }
+    }
+}

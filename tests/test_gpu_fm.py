@@ -164,3 +164,32 @@ def test_fm_nonfinite_sample_stays_local_on_the_matrix_core_stages(bad):
         assert (~np.isfinite(q)).sum() >= 1 and 70 <= nf2.sum() <= 90
     assert np.array_equal(~np.isfinite(a2), nf2)
     assert np.array_equal(a2[~nf2].view(np.uint32), ref[~nf2].view(np.uint32))
+
+
+def test_fm_fused_tail_equals_the_two_kernels(monkeypatch):
+    """De-emphasis + audio resampler in one launch (k_deemph_resample, the default) against the two separate
+    kernels (SDR_FM_TAIL=split, read at create): de-emphasised floats and audio identical bit for bit, over ragged
+    chunks that end inside a workgroup's halo, exactly on a workgroup boundary (4048) and one float beyond it."""
+    fs = 2e6
+    # audio-rate floats per chunk = chunk / 40: 4048 * 40 = 161920 input samples per workgroup span
+    cuts = [0, 40 * 4048, 40 * 4048 + 40, 40 * 4048 + 1960, 40 * 12144 + 17, 40 * 12144 + 57, 700001, 800000]
+    iq = synth.fm_iq(cuts[-1], fs, f_off=-200e3, seed=21)
+    res = {}
+    for mode in ("fused", "split"):
+        if mode == "split":
+            monkeypatch.setenv("SDR_FM_TAIL", "split")
+        else:
+            monkeypatch.delenv("SDR_FM_TAIL", raising=False)
+        with fm.FmRadio(samp_rate=fs, shift=200e3, volume=0.8, max_samples=cuts[-1]) as r:
+            a3, a4 = [], []
+            for a, b in zip(cuts[:-1], cuts[1:]):
+                r.process(iq[a:b])
+                a3.append(r.fetch(3))
+                a4.append(r.fetch(4))
+            res[mode] = (np.concatenate(a3), np.concatenate(a4))
+    for k in range(2):
+        assert res["fused"][k].size == res["split"][k].size > 10000
+        assert np.array_equal(res["fused"][k].view(np.uint32), res["split"][k].view(np.uint32))
+    want = odsp.fm_radio_chain(iq, samp_rate=fs, shift=200e3, volume=0.8)
+    _cmp(res["fused"][0], want[3], exact=False)
+    _cmp(res["fused"][1], want[4], exact=False)

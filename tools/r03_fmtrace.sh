@@ -5,7 +5,7 @@ python3 - <<'PY'
 import csv, glob
 f = max(glob.glob("/tmp/fmtr/**/*kernel_trace.csv", recursive=True), key=lambda p: __import__("os").path.getsize(p))
 rows = [r for r in csv.DictReader(open(f))]
-rows = [r for r in rows if any(k in r["Kernel_Name"] for k in ("mfma2", "k_frontend_win", "k_fir_fff", "k_deemph", "k_resample", "k_tail"))]
+rows = [r for r in rows if any(k in r["Kernel_Name"] for k in ("mfma2", "k_frontend_win", "k_fir_fff", "k_deemph", "k_resample", "k_deemph_resample", "k_tail"))]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 t0 = int(rows[-60]["Start_Timestamp"])
 for r in rows[-60:]:
