@@ -846,6 +846,87 @@ def pfb_segments_workload(torch, dist, dev, rank, world, n=1 << 26, fs=20e6, ste
     return out
 
 
+def long_capture_frames_workload(torch, dist, dev, rank, world, ncat=256, steps=5):
+    """north_star's second multi-GPU case -- "each GPU gets a contiguous segment with FIR-history overlap ... RCCL is
+    used only to gather decoded frames and counts" -- for ONE long TS33C capture (ncat headline captures back to
+    back: 2^26 samples, 2 frames per 2^18): rank r runs the fused chain over its segment (sdr_seek with the halo),
+    the 4-int64 threshold scan gives it its carry-in, it decodes its own bytes (sdr_segment_decode) and hands out its
+    frames plus the run starts of the pieces that touch its ends (segments.gather_frames: one 16-KiB record and the
+    kept frame records per rank); every rank decodes the joined table (sdr_process_runs).  No sliced byte leaves a
+    GPU.  Strong scaling.  Verified on rank 0 against ONE streaming pass over the whole capture on one handle."""
+    from sdr_amd import chain, segments
+    n = ncat * N_PER_CAPTURE
+    iq, _ = make_batch(torch, dev, ncat, seed=777)   # same seed on every rank: every rank holds the capture
+    iq = iq.reshape(n, 2)
+    taps = chain.low_pass(1.0, FS, 20e3, 40e3)
+    a, b = segments.segment_bounds(n, world, DECIM)[rank]
+    max_frames = 4 * ncat
+    c = chain.Chain(FS, decim=DECIM, center_freq=F_OFF, taps=taps, decoder=chain.DEC_TS33C, max_samples=max(b - a, 1),
+                    max_frames=max_frames)
+    c.set_stream(torch.cuda.current_stream().cuda_stream)
+    H = c.history_len()
+    res = {}
+
+    def decode_runs(pos, fl, ll):
+        c.seek(0)
+        c.process_runs(pos, fl, ll)
+        return c.fetch_frames()
+
+    def step():
+        lo = max(0, a - H)
+        c.seek(a, iq[lo:a] if a > lo else None)
+        c.process_iq(iq[a:b])
+        info = c.segment_info()
+        carries, _nb = segments.gather_carries(info.n_bits, info.n_undetermined, info.has_event, info.last_state, world,
+                                               device=dev)
+        pieces = c.segment_decode(carries[rank], 1024)
+        frames = c.fetch_frames() if pieces.n_bits else []
+        res["frames"], res["stats"] = segments.gather_frames(pieces, frames, world, decode_runs, cap=1024, device=dev)
+
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item()) / steps
+    c.close()
+    out = None
+    if rank == 0:
+        if res["frames"] is None:
+            raise SystemExit("long capture: a segment's head / tail table did not fit (flags), stats %s" % res["stats"])
+        got = [(int(f.end_pos), f.status, f.packet()) for f in res["frames"]]
+        whole = chain.Chain(FS, decim=DECIM, center_freq=F_OFF, taps=taps, decoder=chain.DEC_TS33C, max_samples=n,
+                            max_frames=max_frames)
+        whole.process_iq(iq)
+        want = [(int(f.end_pos), f.status, f.packet()) for f in whole.fetch_frames()]
+        whole.close()
+        if got != want or len(want) < 2 * ncat - 2:
+            raise SystemExit("long capture: %d frames by segments, %d by the single pass; first difference %s"
+                             % (len(got), len(want), next(((g, w) for g, w in zip(got, want) if g != w), None)))
+        st = res["stats"]
+        out = {"value": round(n / dt / 1e6, 1), "unit": "Msps", "ms_per_step": round(dt * 1e3, 4), "samples": n,
+               "sample_rate": FS, "n_gpus": world, "scaling": "strong", "segment_samples": b - a, "halo_samples": H,
+               "frames": len(got), "frames_decoded_locally": st["local_frames"], "frames_from_the_joined_table": st["stitched_frames"],
+               "runs_in_the_joined_table": st["runs"], "collective_bytes_per_rank_and_step": 32 + st["payload_bytes"],
+               "chain": "per rank: sdr_seek(halo) -> xlating_fir -> mag2 -> threshold -> slicer on its segment; all_gather of 4 int64 "
+                        "(threshold scan); sdr_segment_decode; all_gather of one 16-KiB run-start record and of the kept frame "
+                        "records; sdr_process_runs on the joined table",
+               "verified": "frames (end position, status, packet) equal ONE streaming pass over the whole capture on rank 0",
+               "note": "host-orchestrated and latency-bound (two read-backs and three small collectives per step); no sliced "
+                       "byte leaves a GPU"}
+    del iq
+    torch.cuda.empty_cache()
+    return out
+
+
 PMC_FILE = "r03_b_pmc.json"   # the committed FETCH_SIZE / WRITE_SIZE passes of the current kernels (tools/profile_round.sh)
 
 
@@ -1222,7 +1303,10 @@ def main():
             progress("wideband_pfb64_segments")
         seg = pfb_segments_workload(torch, dist, dev, rank, world)
         if rank == 0:
-            line["other_workloads"] = {"wideband_pfb64_segments": seg}
+            progress("long_capture_frames_only")
+        lc = long_capture_frames_workload(torch, dist, dev, rank, world)
+        if rank == 0:
+            line["other_workloads"] = {"wideband_pfb64_segments": seg, "long_capture_frames_only": lc}
         dist.destroy_process_group()
         # the CPU leg runs on rank 0 alone, after the process group is gone: no rank waits inside a collective for it
         if rank == 0 and not args.no_cpu_baseline and world > 1:
