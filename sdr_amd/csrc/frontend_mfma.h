@@ -48,16 +48,24 @@ __device__ __forceinline__ void slice_tile_xn(const bool* valid, const float* v,
                                               int8_t* __restrict__ bits, TileSum* __restrict__ ts_out,
                                               int* __restrict__ sh /* 12 ints */, unsigned char* pack = nullptr)
 {
-    int evt[N], has = 0, last = 0, firstk = 0;
+    // Per lane: bit e of H = output e sets the state (v > hi), of K = it clears it (v < lo).  The threshold_ff
+    // recurrence  state_e = H_e | (state_{e-1} & ~K_e)  is the carry chain of an addition (generate = H, propagate =
+    // neither event), so the N states of a lane come from ONE add once its carry-in is known, and "has an event",
+    // "state behind the last event" and "index of the first event" are bit scans -- the per-output select chains of
+    // rounds 1-2 were ~15 vector instructions per output (~190 of the ~1050 per wave on the TFA shape).
+    static_assert(N <= 30, "the carry out of bit N-1 must fit the word");
+    unsigned H = 0, K = 0;
 #pragma unroll
-    for (int e = N - 1; e >= 0; --e) {
-        evt[e] = (valid[e] || (FULL && e > 0)) ? (v[e] > hi ? 1 : (v[e] < lo ? 2 : 0)) : 0;
-        if (evt[e]) {
-            if (!has) last = (evt[e] == 1);
-            has = 1;
-            firstk = e;
-        }
+    for (int e = 0; e < N; ++e) {
+        const bool ok = valid[e] || (FULL && e > 0);
+        const bool up = v[e] > hi;
+        H |= (unsigned)(ok && up) << e;
+        K |= (unsigned)(ok && !up && v[e] < lo) << e;
     }
+    const unsigned E = H | K;
+    const int has = E != 0;
+    const int last = has ? (int)((H >> (31 - __builtin_clz(E | (E == 0)))) & 1u) : 0;
+    const int firstk = has ? __builtin_ctz(E) : 0;
     const unsigned long long any = __ballot(has);
     const unsigned long long sset = __ballot(has && last);
     const int lane = lane_id(), wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
@@ -89,6 +97,10 @@ __device__ __forceinline__ void slice_tile_xn(const bool* valid, const float* v,
         ts_out->first_evt = first < 0 ? -1 : (int32_t)(o_base + first);
         ts_out->last_state = lst;
     }
+    // all N states of the lane: carries of (H | hold) + H + carry-in; bit e+1 of the carry vector = state behind output e
+    constexpr unsigned ALLN = (1u << N) - 1u;
+    const unsigned X = (H | ~E) & ALLN;
+    const unsigned states = (((X + H + (unsigned)st) ^ X ^ H) >> 1) & ALLN;
     const long long ub = o_base - keep_c0;   // uniform: emitted-byte index of the tile's index 0 (keep_n == 1)
     if (FULL) {
         // wave w owns tile indices [64*N*w, 64*N*(w+1)); index 0 is not emitted when valid[0] of thread 0 is false
@@ -99,12 +111,8 @@ __device__ __forceinline__ void slice_tile_xn(const bool* valid, const float* v,
         unsigned char* const wb = pack + wave * (64 * N + 16);
 #pragma unroll
         for (int e = 0; e < N; ++e) {
-            if (evt[e] == 1)
-                st = 1;
-            else if (evt[e] == 2)
-                st = 0;
             const int pos = a + (i0 + e - f);
-            if (e > 0 || pos >= a) wb[pos] = (unsigned char)st;
+            if (e > 0 || pos >= a) wb[pos] = (unsigned char)((states >> e) & 1u);
         }
         // whole dwords [d0, d1) of the image are this wave's alone; the ragged ends go as bytes
         const int d0 = (a + 3) >> 2, d1 = (a + cnt) >> 2;
@@ -119,13 +127,8 @@ __device__ __forceinline__ void slice_tile_xn(const bool* valid, const float* v,
     if (keep_n == 1 && ub >= 0) {           // every tile but a stream's first: no per-lane 64-bit arithmetic
         int8_t* __restrict__ pb = bits + ub;
 #pragma unroll
-        for (int e = 0; e < N; ++e) {
-            if (evt[e] == 1)
-                st = 1;
-            else if (evt[e] == 2)
-                st = 0;
-            if (valid[e]) pb[i0 + e] = (int8_t)st;
-        }
+        for (int e = 0; e < N; ++e)
+            if (valid[e]) pb[i0 + e] = (int8_t)((states >> e) & 1u);
         return;
     }
     // keep_one_in_n: one division per thread (32-bit when the index allows), then
@@ -145,16 +148,13 @@ __device__ __forceinline__ void slice_tile_xn(const bool* valid, const float* v,
     }
 #pragma unroll
     for (int e = 0; e < N; ++e) {
-        if (evt[e] == 1)
-            st = 1;
-        else if (evt[e] == 2)
-            st = 0;
+        const int8_t se = (int8_t)((states >> e) & 1u);
         const long long r = r0 + e;
         if (r < 0) continue;
         if (keep_n == 1) {
-            if (valid[e]) bits[r] = (int8_t)st;
+            if (valid[e]) bits[r] = se;
         } else {
-            if (valid[e] && rem == 0) bits[quo] = (int8_t)st;
+            if (valid[e] && rem == 0) bits[quo] = se;
             if (++rem == keep_n) {
                 rem = 0;
                 ++quo;
