@@ -42,19 +42,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // else uses after this function's barrier: each wavefront lays its 64*N bytes out at the global address's
 // offset inside a dword and writes whole dwords, coalesced (N byte stores per lane at stride N touched every
 // cache line of the run N times: 0.034 of 0.238 ms on the TFA discriminator shape).
-template <int N, bool FULL = false>
-__device__ __forceinline__ void slice_tile_xn(const bool* valid, const float* v, int i0, long long o_base,
-                                              float lo, float hi, int keep_n, long long keep_c0,
-                                              int8_t* __restrict__ bits, TileSum* __restrict__ ts_out,
-                                              int* __restrict__ sh /* 12 ints */, unsigned char* pack = nullptr)
+// per-lane event masks of N outputs: bit e of H = output e sets the state (v > hi), of K = it clears it (v < lo)
+template <int N, bool FULL>
+__device__ __forceinline__ void slice_masks_xn(const bool* valid, const float* v, float lo, float hi, unsigned& H, unsigned& K)
 {
-    // Per lane: bit e of H = output e sets the state (v > hi), of K = it clears it (v < lo).  The threshold_ff
-    // recurrence  state_e = H_e | (state_{e-1} & ~K_e)  is the carry chain of an addition (generate = H, propagate =
-    // neither event), so the N states of a lane come from ONE add once its carry-in is known, and "has an event",
-    // "state behind the last event" and "index of the first event" are bit scans -- the per-output select chains of
-    // rounds 1-2 were ~15 vector instructions per output (~190 of the ~1050 per wave on the TFA shape).
-    static_assert(N <= 30, "the carry out of bit N-1 must fit the word");
-    unsigned H = 0, K = 0;
+    H = 0;
+    K = 0;
 #pragma unroll
     for (int e = 0; e < N; ++e) {
         const bool ok = valid[e] || (FULL && e > 0);
@@ -62,6 +55,21 @@ __device__ __forceinline__ void slice_tile_xn(const bool* valid, const float* v,
         H |= (unsigned)(ok && up) << e;
         K |= (unsigned)(ok && !up && v[e] < lo) << e;
     }
+}
+
+// The slicer proper, from the masks (a caller that knows the class of an output without its value -- the
+// threshold-only discriminator -- builds them itself).
+// The threshold_ff recurrence  state_e = H_e | (state_{e-1} & ~K_e)  is the carry chain of an addition (generate = H,
+// propagate = neither event), so the N states of a lane come from ONE add once its carry-in is known, and "has an
+// event", "state behind the last event" and "index of the first event" are bit scans -- the per-output select chains
+// of rounds 1-2 were ~15 vector instructions per output (~190 of the ~1050 per wave on the TFA shape).
+template <int N, bool FULL = false>
+__device__ __forceinline__ void slice_tile_hk(const bool* valid, const unsigned H, const unsigned K, int i0, long long o_base,
+                                              int keep_n, long long keep_c0,
+                                              int8_t* __restrict__ bits, TileSum* __restrict__ ts_out,
+                                              int* __restrict__ sh /* 12 ints */, unsigned char* pack = nullptr)
+{
+    static_assert(N <= 30, "the carry out of bit N-1 must fit the word");
     const unsigned E = H | K;
     const int has = E != 0;
     const int last = has ? (int)((H >> (31 - __builtin_clz(E | (E == 0)))) & 1u) : 0;
@@ -161,6 +169,17 @@ __device__ __forceinline__ void slice_tile_xn(const bool* valid, const float* v,
             }
         }
     }
+}
+
+template <int N, bool FULL = false>
+__device__ __forceinline__ void slice_tile_xn(const bool* valid, const float* v, int i0, long long o_base,
+                                              float lo, float hi, int keep_n, long long keep_c0,
+                                              int8_t* __restrict__ bits, TileSum* __restrict__ ts_out,
+                                              int* __restrict__ sh /* 12 ints */, unsigned char* pack = nullptr)
+{
+    unsigned H, K;
+    slice_masks_xn<N, FULL>(valid, v, lo, hi, H, K);
+    slice_tile_hk<N, FULL>(valid, H, K, i0, o_base, keep_n, keep_c0, bits, ts_out, sh, pack);
 }
 
 // The K loop of one wavefront: 256 outputs (16 groups x 16) from the padded sample image `smp` and the tap
