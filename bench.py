@@ -239,7 +239,7 @@ def fm_workload(torch, dev, skip_cpu, n=1 << 26, fs=2.4e6, steps=10):
            "sample_rate": fs, "audio_samples": int(na),
            "chain": "xlating->resample 1/4->lpf->quadrature_demod->audio fir /10->deemph 75us->resample 24/25 (streaming state carried)",
            "roofline": {"bound": "mfma", "kernel": "whole chain: k_frontend_mfma (rotate + 131 taps /4) + k_frontend_win (33 taps, "
-                        "discriminator) + k_fir_fff_mfma (771 taps /10) + k_deemph_warm + k_resample_fff",
+                        "discriminator) + k_fir_fff_mfma (771 taps /10) + k_deemph_resample (de-emphasis + 24/25 resampler)",
                         "achieved": round(tf, 1), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(tf / FP32_PEAK_TFLOPS, 4), "traffic": fm_traffic, "traffic_source": fm_traffic_src, "kernel_ms": round(gpu_ms, 4),
                         "flops_per_launch": fps * n, "hbm_achieved_gbs": round(ach, 1), "hbm_frac": round(ach / HBM_PEAK_GBS, 4),
@@ -927,7 +927,7 @@ def long_capture_frames_workload(torch, dist, dev, rank, world, ncat=256, steps=
     return out
 
 
-PMC_FILE = "r03_b_pmc.json"   # the committed FETCH_SIZE / WRITE_SIZE passes of the current kernels (tools/profile_round.sh)
+PMC_FILE = "r03_c_pmc.json"   # the committed FETCH_SIZE / WRITE_SIZE passes of the current kernels (tools/profile_round.sh)
 
 
 def progress(msg):

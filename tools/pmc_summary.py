@@ -47,6 +47,7 @@ def main(fetch_csv, write_csv, out_json):
             ("k_fm_stage_ab", "fm stages A+B k_fm_stage_ab", 8.0 * fm_n + 4.0 * fm_n / 4, 8.0 * fm_n, "fm_radio_wbfm samples=2^26", 2),
             ("k_fir_fff_mfma", "fm audio FIR k_fir_fff_mfma", 4.0 * fm_n / 4 + 4.0 * fm_n / 40, 4.0 * fm_n / 4, "fm_radio_wbfm samples=2^26", 2),
             ("k_fm_audio", "fm audio FIR + de-emphasis + resampler k_fm_audio", 4.0 * fm_n / 4 + 4.0 * fm_n / 40 * 0.96, 4.0 * fm_n / 4, "fm_radio_wbfm samples=2^26", 2),
+            ("k_deemph_resample", "fm de-emphasis + resampler k_deemph_resample", 4.0 * fm_n / 40 * 2.96, 4.0 * fm_n / 40, "fm_radio_wbfm samples=2^26", 1),
             ("k_deemph_warm", "fm de-emphasis k_deemph_warm", 8.0 * fm_n / 40, 4.0 * fm_n / 40, "fm_radio_wbfm samples=2^26", 1),
             ("k_resample_fff_lds", "fm resampler k_resample_fff_lds", 4.0 * fm_n / 40 * 1.96, 4.0 * fm_n / 40, "fm_radio_wbfm samples=2^26", 1),
             ("k_tail_update_batch", "fm history update k_tail_update_batch", 0.0, 1.0, "fm_radio_wbfm samples=2^26", 1)]
