@@ -248,20 +248,28 @@ __global__ void __launch_bounds__(256) k_pfb(PfbParams Q)
         }
         return;
     }
-    unsigned states = 0;   // bit i = threshold_ff output at time i, carry-in 0
-    int first = -1, st = 0;
+    // threshold_ff over the lane's 16 outputs as an adder's carry chain (see slice_tile_hk in frontend_mfma.h):
+    // bit i of H / K = output i sets / clears the state; outputs past the row's end carry no event (uniform mask)
+    unsigned H = 0, K = 0;
 #pragma unroll
     for (int i = 0; i < PFB_TM; ++i) {
-        float v = Q.gain * __builtin_fmaf(ar[i], ar[i], ai[i] * ai[i]);
+        const float v = Q.gain * __builtin_fmaf(ar[i], ar[i], ai[i] * ai[i]);
         ar[i] = v;
-        const bool valid = o_w + i < Q.nout;
-        const int evt = valid ? (v > Q.hi ? 1 : (v < Q.lo ? 2 : 0)) : 0;
-        if (evt) {
-            if (first < 0) first = i;
-            st = evt == 1;
-        }
-        states |= (unsigned)st << i;
+        const bool up = v > Q.hi;
+        H |= (unsigned)up << i;
+        K |= (unsigned)(!up && v < Q.lo) << i;
     }
+    {
+        const long long left = Q.nout - o_w;
+        const unsigned vm = left >= PFB_TM ? 0xffffu : (left <= 0 ? 0u : ((1u << (int)left) - 1u));
+        H &= vm;
+        K &= vm;
+    }
+    const unsigned E = H | K;
+    const int first = E ? __builtin_ctz(E) : -1;
+    const int st = E ? (int)((H >> (31 - __builtin_clz(E))) & 1u) : 0;
+    const unsigned X = (H | ~E) & 0xffffu;
+    unsigned states = (((X + H) ^ X ^ H) >> 1) & 0xffffu;   // bit i = threshold_ff output at time i, carry-in 0
     if (Q.tap) {
         float* dst = Q.tap + row * Q.tap_stride;
 #pragma unroll
