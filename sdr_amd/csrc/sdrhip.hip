@@ -2233,6 +2233,7 @@ extern "C" int sdr_export_bits(sdr_handle* h, void* bits_dev, size_t cap_bytes, 
 }
 
 // ------------------------------------------------------------------ one long capture, frames-only exchange
+static_assert(sizeof(sdr_segment_pieces) == 56, "sdr_segment_pieces is mirrored field by field in sdr_amd/_lib.py");
 // SURVEY 8e / north_star "RCCL ... used only to gather decoded frames and counts".  The stream decoder
 // (TS33C/stream_decoder.py:76-110) cuts the symbol stream behind every width above reset_limit and decodes each
 // closed piece from an empty currentSymbols, so a rank can decode the pieces that lie wholly inside its segment

@@ -28,6 +28,7 @@ def test_struct_mirrors_match_header_sizes():
     assert C.sizeof(_lib.ChainCfg) == 80
     assert C.sizeof(_lib.Out) == 32
     assert C.sizeof(_lib.PreambleInfo) == 32
+    assert C.sizeof(_lib.SegmentPieces) == 56 and C.sizeof(_lib.SegmentInfo) == 40
     assert _lib.load().sdr_version() >= 100
 
 
