@@ -34,13 +34,16 @@ typedef float win_v2f __attribute__((ext_vector_type(2)));
 
 // Epilogue of one tile.  FULL: every output of the tile exists and is emitted (but tile index 0 of a
 // discriminator tile, which is the previous tile's last output); if the chain slices, keep_n == 1.
-template <bool FULL>
+// DM (compile time): 0 = the demodulator is read from P.demod; SDR_DEMOD_MAG2 = this instantiation serves mag^2
+// chains only (no discriminator code, no arctangent table: fewer registers, one more wave per SIMD)
+template <bool FULL, int DM>
 __device__ __forceinline__ void win_epilogue(const FrontParams& P, const int tile, const int cap, win_v2f* acc,
                                              const long long m_t0, const int i_lo, const int i_hi, const int q, int* sh,
                                              const float* s_atan, float2* s_edge, unsigned char* pack)
 {
     constexpr int R = WIN_R;
     typedef win_v2f v2f;
+    const int demod = DM ? DM : P.demod;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const long long m0 = m_t0 + (long long)R * t;
     bool valid[R];
@@ -64,7 +67,7 @@ __device__ __forceinline__ void win_epilogue(const FrontParams& P, const int til
             ph += P.nco_inc;
         }
     }
-    if (P.demod == SDR_DEMOD_NONE) {
+    if (demod == SDR_DEMOD_NONE) {
         if (P.tap) {
             float2* dst = reinterpret_cast<float2*>(P.tap + (long long)cap * P.tap_stride);
 #pragma unroll
@@ -74,7 +77,7 @@ __device__ __forceinline__ void win_epilogue(const FrontParams& P, const int til
         return;
     }
     float v[R];
-    if (P.demod == SDR_DEMOD_MAG2) {
+    if (demod == SDR_DEMOD_MAG2) {
 #pragma unroll
         for (int r = 0; r < R; ++r) v[r] = __builtin_fmaf(acc[r].x, acc[r].x, acc[r].y * acc[r].y);
     } else {
@@ -133,7 +136,7 @@ __device__ __forceinline__ void win_epilogue(const FrontParams& P, const int til
             }
         }
     }
-    if (P.demod == SDR_DEMOD_MAG2) {
+    if (demod == SDR_DEMOD_MAG2) {
 #pragma unroll
         for (int r = 0; r < R; ++r) v[r] = P.gain * v[r];
     }
@@ -169,14 +172,15 @@ __device__ __forceinline__ void win_epilogue(const FrontParams& P, const int til
 // CPLX: complex taps (rtaps = interleaved re,im): per tap and output two packed fmas in the oracle's order,
 //   (re, im) += a * (x.re, x.im);   (re, im) += (-b, b) * (x.im, x.re)        tap = a + jb
 // the halves of the tap pair and the swapped sample picked by op_sel, the sign by neg_lo: no extra moves.
-template <bool CPLX>
+template <bool CPLX, int DM>
 __device__ __forceinline__ void win_tile(const FrontParams& P, const int tile, const int cap, unsigned char* smem_raw,
                                          int* sh, const float* s_atan, float2* s_edge)
 {
+    const int demod = DM ? DM : P.demod;
     constexpr int R = WIN_R, W = WIN_W;
     const int T = blockDim.x, t = threadIdx.x, lane = t & 63;
     const int nt = P.ntaps, H = nt - 1;
-    const int q = (P.demod == SDR_DEMOD_QUAD) ? 1 : 0;
+    const int q = (demod == SDR_DEMOD_QUAD) ? 1 : 0;
     const int ntl = win_tap_floats(nt, CPLX);
     float* const tapL = reinterpret_cast<float*>(smem_raw);
     float2* const lds = reinterpret_cast<float2*>(tapL + ntl);
@@ -374,12 +378,12 @@ __device__ __forceinline__ void win_tile(const FrontParams& P, const int tile, c
     const int i_lo = (P.hist != nullptr || m_t0 >= 0) ? 0 : (int)(-m_t0);
     // interior tile of a slicing chain that keeps every byte: no per-output masks, packed byte stores
     // ... or of a chain that only keeps the demodulated floats (FM stage B)
-    const bool full = i_lo == 0 && i_hi == T * R && P.demod != SDR_DEMOD_NONE &&
+    const bool full = i_lo == 0 && i_hi == T * R && demod != SDR_DEMOD_NONE &&
                       (P.do_slice ? (P.keep_n == 1 && m_t0 - P.keep_c0 >= 0) : P.tap != nullptr);
     if (full)
-        win_epilogue<true>(P, tile, cap, acc, m_t0, i_lo, i_hi, q, sh, s_atan, s_edge, reinterpret_cast<unsigned char*>(lds));
+        win_epilogue<true, DM>(P, tile, cap, acc, m_t0, i_lo, i_hi, q, sh, s_atan, s_edge, reinterpret_cast<unsigned char*>(lds));
     else
-        win_epilogue<false>(P, tile, cap, acc, m_t0, i_lo, i_hi, q, sh, s_atan, s_edge, nullptr);
+        win_epilogue<false, DM>(P, tile, cap, acc, m_t0, i_lo, i_hi, q, sh, s_atan, s_edge, nullptr);
 }
 
 // blockDim.x = T (64 or 256), P.D == 1, real taps, P.tile_out = T*WIN_R - q; one tile per workgroup.
@@ -388,14 +392,14 @@ __device__ __forceinline__ void win_tile(const FrontParams& P, const int tile, c
 // in the epilogue so that nothing waits for it: 0.339 ms against 0.285 on the TFA shape, 0.308 against 0.251 on
 // the R shape -- two buffers are 43 KB of LDS, 3 workgroups per CU instead of 7, and this kernel lives on its
 // 28 resident waves hiding each other's LDS and fma latencies, not on prefetch.)
-template <bool CPLX>
-__global__ void __launch_bounds__(256) k_frontend_win(FrontParams P)
+template <bool CPLX, int DM>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DM == SDR_DEMOD_MAG2 ? 6 : 1))) k_frontend_win(FrontParams P)
 {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     __shared__ int sh[12];
-    __shared__ float s_atan[257];
+    __shared__ float s_atan[DM == SDR_DEMOD_MAG2 ? 1 : 257];
     __shared__ float2 s_edge[4];
-    if (P.demod == SDR_DEMOD_QUAD)
+    if (DM != SDR_DEMOD_MAG2 && P.demod == SDR_DEMOD_QUAD)
         for (int i = threadIdx.x; i < 257; i += blockDim.x) s_atan[i] = P.atan_tab[i];
-    win_tile<CPLX>(P, blockIdx.x, blockIdx.y, smem_raw, sh, s_atan, s_edge);
+    win_tile<CPLX, DM>(P, blockIdx.x, blockIdx.y, smem_raw, sh, s_atan, s_edge);
 }

@@ -1222,9 +1222,15 @@ static int launch_front(sdr_handle* h, const float2* x, long long stride, long l
         return fail(h, SDR_E_ARG, "demod NONE needs cfg.tap_demod (complex output buffer)");
     dim3 grid(g.tiles, ncap), block(g.T);
     if (g.win && P.taps_complex)
-        hipLaunchKernelGGL(k_frontend_win<true>, grid, block, g.lds, h->stream, P);
+        if (P.demod == SDR_DEMOD_MAG2)
+            hipLaunchKernelGGL((k_frontend_win<true, SDR_DEMOD_MAG2>), grid, block, g.lds, h->stream, P);
+        else
+            hipLaunchKernelGGL((k_frontend_win<true, 0>), grid, block, g.lds, h->stream, P);
     else if (g.win)
-        hipLaunchKernelGGL(k_frontend_win<false>, grid, block, g.lds, h->stream, P);
+        if (P.demod == SDR_DEMOD_MAG2)
+            hipLaunchKernelGGL((k_frontend_win<false, SDR_DEMOD_MAG2>), grid, block, g.lds, h->stream, P);
+        else
+            hipLaunchKernelGGL((k_frontend_win<false, 0>), grid, block, g.lds, h->stream, P);
     else if (g.mfma && g.mfma2) {
         dim3 dgrid((g.tiles + g.mfma2 - 1) / g.mfma2, ncap);
         hipLaunchKernelGGL(k_frontend_mfma2, dgrid, dim3(512), g.mfma2_lds, h->stream, P, g.mfma2);
