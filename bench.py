@@ -238,7 +238,7 @@ def fm_workload(torch, dev, skip_cpu, n=1 << 26, fs=2.4e6, steps=10):
     out = {"value": round(n / dt / 1e6, 1), "unit": "Msps", "ms_per_step": round(dt * 1e3, 4), "samples": n,
            "sample_rate": fs, "audio_samples": int(na),
            "chain": "xlating->resample 1/4->lpf->quadrature_demod->audio fir /10->deemph 75us->resample 24/25 (streaming state carried)",
-           "roofline": {"bound": "mfma", "kernel": "whole chain: k_frontend_mfma (rotate + 131 taps /4) + k_frontend_win (33 taps, "
+           "roofline": {"bound": "mfma", "kernel": "whole chain: k_frontend_mfma2 (rotate + 131 taps /4) + k_frontend_win (33 taps, "
                         "discriminator) + k_fir_fff_mfma (771 taps /10) + k_deemph_resample (de-emphasis + 24/25 resampler)",
                         "achieved": round(tf, 1), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(tf / FP32_PEAK_TFLOPS, 4), "traffic": fm_traffic, "traffic_source": fm_traffic_src, "kernel_ms": round(gpu_ms, 4),

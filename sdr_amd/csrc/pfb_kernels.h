@@ -101,11 +101,18 @@ __global__ void __launch_bounds__(256) k_pfb(PfbParams Q)
         const int pairs = (count + odd + 1) >> 1;
         lsh = odd;
         // (two loops: the DMA loop holds no other memory operation, see k_frontend)
+        // chunk p holds samples lo_al + 2p, +1: inside the capture for p in [plo, phi) -- uniform bounds, so a lane
+        // tests two 32-bit numbers and adds a 32-bit offset to a uniform base (as k_frontend_win)
+        long long plo64 = lo_al < 0 ? (1 - lo_al) >> 1 : 0, phi64 = (Q.n - lo_al) >> 1;
+        if (plo64 > pairs) plo64 = pairs;
+        if (phi64 > pairs) phi64 = pairs;
+        if (phi64 < plo64) phi64 = plo64;
+        const int plo = (int)plo64, phi = (int)phi64;
+        const char* __restrict__ xb = reinterpret_cast<const char*>(x + lo_al);
         for (int p0 = (threadIdx.x & ~63); p0 < pairs; p0 += 256) {
             const int p = p0 + lane;
-            const long long s = lo_al + 2LL * p;
-            if (p < pairs && s >= 0 && s + 2 <= Q.n)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(x + s),
+            if (p >= plo && p < phi)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xb + (unsigned)(16 * p)),
                                                  (__attribute__((address_space(3))) void*)(lds + 2 * p0), 16, 0, SDR_GLDS_AUX);
         }
         if (lo_al < 0 || lo_al + 2LL * pairs > Q.n) {   // uniform: only edge tiles have guarded chunks
