@@ -110,7 +110,7 @@ static int pfb_launch(sdr_handle* h, const float2* x, long long stride, long lon
     Q.tiles_per_row = g.tiles;
     size_t lds = ((size_t)(h->pfb_P + PFB_TILE - 1) * PFB_M + 2) * sizeof(float2);
     if (lds < (size_t)PFB_NW * PFB_SLAB * sizeof(float2)) lds = (size_t)PFB_NW * PFB_SLAB * sizeof(float2);
-    dim3 grid(g.tiles, ncap), block(256);
+    dim3 grid(g.tiles, ncap), block(PFB_THREADS);
     switch (h->pfb_P) {
     case 4: hipLaunchKernelGGL(k_pfb<4>, grid, block, lds, h->stream, Q); break;
     case 8: hipLaunchKernelGGL(k_pfb<8>, grid, block, lds, h->stream, Q); break;

@@ -30,7 +30,10 @@
 
 #define PFB_M 64
 #define PFB_TM 16    // output times per wave
+#ifndef PFB_NW
 #define PFB_NW 4     // waves per workgroup
+#endif
+#define PFB_THREADS (64 * PFB_NW)
 #define PFB_TILE (PFB_TM * PFB_NW)
 #define PFB_VP 68     // row pitch (float2) of the V/U transposes: 16 rows per wave
 #define PFB_YP 17     // row pitch of the Y transpose: 64 rows per wave
@@ -60,7 +63,7 @@ struct PfbParams {
 };
 
 template <int P>
-__global__ void __launch_bounds__(256) k_pfb(PfbParams Q)
+__global__ void __launch_bounds__(PFB_THREADS) k_pfb(PfbParams Q)
 {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     float2* lds = reinterpret_cast<float2*>(smem_raw);
@@ -109,14 +112,14 @@ __global__ void __launch_bounds__(256) k_pfb(PfbParams Q)
         if (phi64 < plo64) phi64 = plo64;
         const int plo = (int)plo64, phi = (int)phi64;
         const char* __restrict__ xb = reinterpret_cast<const char*>(x + lo_al);
-        for (int p0 = (threadIdx.x & ~63); p0 < pairs; p0 += 256) {
+        for (int p0 = (threadIdx.x & ~63); p0 < pairs; p0 += PFB_THREADS) {
             const int p = p0 + lane;
             if (p >= plo && p < phi)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xb + (unsigned)(16 * p)),
                                                  (__attribute__((address_space(3))) void*)(lds + 2 * p0), 16, 0, SDR_GLDS_AUX);
         }
         if (lo_al < 0 || lo_al + 2LL * pairs > Q.n) {   // uniform: only edge tiles have guarded chunks
-            for (int p = threadIdx.x; p < pairs; p += 256) {
+            for (int p = threadIdx.x; p < pairs; p += PFB_THREADS) {
                 const long long s = lo_al + 2LL * p;
                 if (!(s >= 0 && s + 2 <= Q.n)) {
                     lds[2 * p] = fetch(s);
@@ -125,7 +128,7 @@ __global__ void __launch_bounds__(256) k_pfb(PfbParams Q)
             }
         }
     } else {
-        for (int i = threadIdx.x; i < count; i += 256) lds[i] = fetch(lo_idx + i);
+        for (int i = threadIdx.x; i < count; i += PFB_THREADS) lds[i] = fetch(lo_idx + i);
     }
 
     // branch taps of this lane, twiddles of this lane for the six stages
