@@ -35,8 +35,8 @@ def main(fetch_csv, write_csv, out_json):
     fm_n = 1 << 26
     # (kernel substring, key, algorithmic bytes, algorithmic READ bytes that pick the launch group, workload,
     #  fetch correction: 2 = 16-B/lane streaming reads (calibrated), 1 = other widths (uncalibrated, reported as counted))
-    want = [("k_frontend<true, false>", "k_frontend<true, false> fc32", 8.02 * n, 8.0 * n, "ook_batch_ts33c_xlating captures_per_gpu=1250", 2),
-            ("k_frontend<true, false>", "k_frontend<true, false> fc32 D=10", 8.1 * n, 8.0 * n * 1.024, "ook_batch_somfy_berner_mumbi captures=1250", 2),
+    want = [("k_frontend<true, false,", "k_frontend<true, false> fc32", 8.02 * n, 8.0 * n, "ook_batch_ts33c_xlating captures_per_gpu=1250", 2),
+            ("k_frontend<true, false,", "k_frontend<true, false> fc32 D=10", 8.1 * n, 8.0 * n * 1.024, "ook_batch_somfy_berner_mumbi captures=1250", 2),
             ("k_frontend_raw8", "k_frontend_raw8 cu8", 2.02 * n, 2.0 * n, "ook_batch_cu8 captures_per_gpu=1250", 2),
             ("k_pfb<8>", "k_pfb<8>", (8 + 1 / 16) * (1 << 26), 8.0 * (1 << 26), "wideband_pfb64 samples=2^26", 2),
             ("k_frontend_win", "k_frontend_win tfa", 9.0 * 64 * (1 << 20), 8.0 * 64 * (1 << 20), "tfa_fsk_discriminator captures=64", 2),
