@@ -300,3 +300,38 @@ def test_process_runs_is_one_work_call():
             b.process_runs(np.array([0, 5, 5, 9], np.int32), 0, 0)
         with pytest.raises(_lib_err()):
             b.process_runs(np.array([0, 9], np.int32), 0, 0)      # shorter than reset_limit
+
+
+@pytest.mark.parametrize("fmt,fc", [("fc32", 100e3), ("cu8", 0.0)])
+def test_frames_only_exchange_xlating_and_cu8(fmt, fc):
+    """the same with a translated channel (NCO phase set by sdr_seek) and with rtl-sdr bytes as input"""
+    from oracle import dsp as odsp
+    rng = np.random.default_rng(5)
+    sym = []
+    for k in range(5):
+        pkt = synth.ts33c_packet(**synth.random_ts33c_fields(rng))
+        sym += synth.ts33c_symbols(synth.ts33c_bits(pkt), rng)
+    env = np.concatenate([synth.envelope(sym, FS, lead_in_us=3000.0), np.zeros(4000, np.uint8)])
+    iq = synth.ook_iq(env, FS, f_off=fc, amp=0.7, sigma=0.02, rng=rng)
+    n = iq.size
+    taps = _taps()
+    D = 50
+    kw = dict(decim=D, taps=taps, keep_n=1, center_freq=fc, decoder=chain.DEC_TS33C, max_samples=n, max_frames=32)
+    if fmt == "cu8":
+        u8 = np.clip(np.round(iq.view(np.float32) * 128.0 + 127.4), 0, 255).astype(np.uint8).reshape(n, 2)
+        x = u8
+        xf = ((u8.astype(np.float32) - np.float32(127.4)) / np.float32(128.0)).view(np.complex64).reshape(n)
+        kw["input_format"] = "cu8"
+    else:
+        x, xf = iq, iq
+    want_bits = odsp.ook_chain(xf, taps, D, 1.0, 0.05, 0.15, 1, fc=fc, fs=FS)
+    o = odec.TS33CStreamDecoder(sample_rate=FS / D)
+    o.work([want_bits])
+    want = [_okey(f) for f in o.frames]
+    assert len(want) >= 4
+    inner = sorted(int(v) // D * D for v in rng.integers(D, n - D, 5))
+    cuts = [0] + inner + [n]
+    with chain.Chain(FS, **kw) as c:
+        got, stats = segments.frames_only(c, x, list(zip(cuts[:-1], cuts[1:])))
+        assert not stats["fallback"]
+        assert [_key(f) for f in got] == want, cuts
