@@ -1053,6 +1053,29 @@ def launch_ranks(n, argv, rehearsal):
     return rc
 
 
+def stage_collectives_through_host(torch, dist):
+    """SDR_BENCH_REHEARSAL=gloo-gpu only: gloo moves host tensors, so the collectives this file and sdr_amd use
+    (all_gather_into_tensor, all_reduce) copy a GPU tensor to the host, run there and copy the result back."""
+    ag, ar = dist.all_gather_into_tensor, dist.all_reduce
+
+    def all_gather_into_tensor(out, inp, *a, **k):
+        if not inp.is_cuda:
+            return ag(out, inp, *a, **k)
+        o = torch.empty(out.shape, dtype=out.dtype)
+        ag(o, inp.cpu(), *a, **k)
+        out.copy_(o)
+
+    def all_reduce(t, *a, **k):
+        if not t.is_cuda:
+            return ar(t, *a, **k)
+        h = t.cpu()
+        ar(h, *a, **k)
+        t.copy_(h)
+
+    dist.all_gather_into_tensor = all_gather_into_tensor
+    dist.all_reduce = all_reduce
+
+
 def _oracle_low_pass():
     """the headline's channel filter from the oracle's firdes (the rehearsal has no GPU library to ask)"""
     from oracle import dsp as odsp
@@ -1112,11 +1135,15 @@ def main():
     if args.cpu_worker:
         return cpu_worker(args.cpu_worker[0], int(args.cpu_worker[1]), int(args.cpu_worker[2]), float(args.cpu_worker[3]))
     rehearsal = os.environ.get("SDR_BENCH_REHEARSAL") == "gloo"
+    # SDR_BENCH_REHEARSAL=gloo-gpu: the real multi-rank run (every workload, every kernel, every check) with N ranks
+    # that SHARE GPU 0 and a gloo process group whose collectives are staged through the host -- what a one-GPU box
+    # can show of the N > 1 path.  Its timings mean nothing and the line says so.
+    shared_gpu = os.environ.get("SDR_BENCH_REHEARSAL") == "gloo-gpu"
     if args.gpus < 1:
         raise SystemExit("bench.py: --gpus must be >= 1")
     if "WORLD_SIZE" not in os.environ:
         if args.gpus > 1:
-            sys.exit(launch_ranks(args.gpus, sys.argv[1:], rehearsal))
+            sys.exit(launch_ranks(args.gpus, sys.argv[1:], rehearsal or shared_gpu))
     elif int(os.environ["WORLD_SIZE"]) != args.gpus:
         raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%s ranks" % (args.gpus, os.environ["WORLD_SIZE"]))
     if rehearsal:
@@ -1129,7 +1156,7 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = 0 if shared_gpu else int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU path)")
     torch.cuda.set_device(local)
@@ -1142,7 +1169,10 @@ def main():
     # SDR_BENCH_DIST=1 under torchrun with ONE rank walks the multi-GPU code (RCCL init, frame gather,
     # barriers, max over ranks) on a one-GPU box
     use_dist = world > 1 or (os.environ.get("SDR_BENCH_DIST") == "1" and "MASTER_ADDR" in os.environ)
-    if use_dist:
+    if use_dist and shared_gpu:
+        dist.init_process_group("gloo")
+        stage_collectives_through_host(torch, dist)
+    elif use_dist:
         dist.init_process_group("nccl", device_id=dev)
 
     ncap = args.captures
@@ -1272,6 +1302,8 @@ def main():
                          "bytes_per_launch": BYTES_PER_SAMPLE * samples_per_step},
             "frames_decoded": len(frames) * world, "verified": "all captures decode to the transmitted packets; 3 captures bit-exact vs oracle",
         }
+        if shared_gpu:
+            line["rehearsal"] = "%d gloo ranks sharing GPU 0, collectives staged through the host: a check of the N > 1 path, no timing here is a measurement" % world
         per_rank = [BYTES_PER_SAMPLE * samples_per_step / (k * 1e-3) / 1e9 / HBM_PEAK_GBS for k in rank_fk]
         line["roofline"].update({"frac_min": round(min(per_rank), 4), "frac_max": round(max(per_rank), 4),
                                  "kernel_ms_per_rank": [round(k, 4) for k in rank_fk]})
