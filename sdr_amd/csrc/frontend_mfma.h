@@ -48,9 +48,23 @@ __device__ __forceinline__ void slice_masks_xn(const bool* valid, const float* v
 {
     H = 0;
     K = 0;
+    if (FULL) {
+        // two instructions per output and mask: the compare's lane bit enters the mask as the carry of mask + mask
+        // (outputs walked from the last to the first); the compiler's form -- compare, select 1 << e, or -- took ~7
+        // per output for both masks.  "not above hi" and valid[0] are applied to the finished masks.
+#pragma unroll
+        for (int e = N - 1; e >= 0; --e) {
+            asm("v_cmp_lt_f32_e32 vcc, %1, %2\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(H) : "s"(hi), "v"(v[e]) : "vcc");
+            asm("v_cmp_gt_f32_e32 vcc, %1, %2\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(K) : "s"(lo), "v"(v[e]) : "vcc");
+        }
+        const unsigned keep = valid[0] ? ~0u : ~1u;
+        H &= keep;
+        K &= ~H & keep;
+        return;
+    }
 #pragma unroll
     for (int e = 0; e < N; ++e) {
-        const bool ok = valid[e] || (FULL && e > 0);
+        const bool ok = valid[e];
         const bool up = v[e] > hi;
         H |= (unsigned)(ok && up) << e;
         K |= (unsigned)(ok && !up && v[e] < lo) << e;
@@ -117,10 +131,28 @@ __device__ __forceinline__ void slice_tile_hk(const bool* valid, const unsigned 
         int8_t* const G = bits + ub + f;                                        // first byte of this wave's run
         const int a = (int)(reinterpret_cast<uintptr_t>(G) & 3);
         unsigned char* const wb = pack + wave * (64 * N + 16);
+        // the lane's N bytes: four state bits become four bytes by one multiplication ((x & 15) * 0x204081 puts bit k
+        // of x at bit 8k, the shifted copies do not overlap); outputs 1.. leave as unaligned 8-/4-/1-byte LDS writes
+        const int pos0 = a + (i0 - f);
+        if (pos0 >= a) wb[pos0] = (unsigned char)(states & 1u);
+        typedef unsigned long long u64u __attribute__((aligned(1)));
+        typedef unsigned u32u __attribute__((aligned(1)));
+        auto spread4 = [](unsigned x) -> unsigned { return ((x & 15u) * 0x00204081u) & 0x01010101u; };
+        constexpr int N8 = (N - 1) / 8, N4 = ((N - 1) - 8 * N8) / 4, N1 = (N - 1) - 8 * N8 - 4 * N4;
 #pragma unroll
-        for (int e = 0; e < N; ++e) {
-            const int pos = a + (i0 + e - f);
-            if (e > 0 || pos >= a) wb[pos] = (unsigned char)((states >> e) & 1u);
+        for (int g = 0; g < N8; ++g) {
+            const int e = 1 + 8 * g;
+            *reinterpret_cast<u64u*>(wb + pos0 + e) = (unsigned long long)spread4(states >> e) | ((unsigned long long)spread4(states >> (e + 4)) << 32);
+        }
+#pragma unroll
+        for (int g = 0; g < N4; ++g) {
+            const int e = 1 + 8 * N8 + 4 * g;
+            *reinterpret_cast<u32u*>(wb + pos0 + e) = spread4(states >> e);
+        }
+#pragma unroll
+        for (int g = 0; g < N1; ++g) {
+            const int e = 1 + 8 * N8 + 4 * N4 + g;
+            wb[pos0 + e] = (unsigned char)((states >> e) & 1u);
         }
         // whole dwords [d0, d1) of the image are this wave's alone; the ragged ends go as bytes
         const int d0 = (a + 3) >> 2, d1 = (a + cnt) >> 2;

@@ -261,11 +261,15 @@ __device__ __forceinline__ void win_tile(const FrontParams& P, const int tile, c
         if (phi64 > pairs) phi64 = pairs;
         if (phi64 < plo64) phi64 = plo64;
         const int plo = (int)plo64, phi = (int)phi64;
-        const char* __restrict__ xb = reinterpret_cast<const char*>(x + lo_al);
-        for (int p0 = (t & ~63); p0 < pairs; p0 += T) {
+        // the wave's first chunk as a scalar: the LDS base of every DMA (M0) and the loop counter stay in scalar
+        // registers, a lane keeps one 64-bit pointer and bumps it (11 vector instructions per DMA before, 4 now)
+        const int wb = __builtin_amdgcn_readfirstlane(t & ~63);
+        const char* __restrict__ gp = reinterpret_cast<const char*>(x + lo_al) + 16u * (unsigned)(wb + lane);
+        const unsigned gstep = 16u * (unsigned)T;
+        for (int p0 = wb; p0 < pairs; p0 += T, gp += gstep) {
             const int p = p0 + lane;
             if (p >= plo && p < phi)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xb + (unsigned)(16 * p)),
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
                                                  (__attribute__((address_space(3))) void*)(lds + 2 * p0), 16, 0,
                                                  SDR_GLDS_AUX);
         }
