@@ -111,11 +111,12 @@ __global__ void __launch_bounds__(PFB_THREADS) k_pfb(PfbParams Q)
         if (phi64 > pairs) phi64 = pairs;
         if (phi64 < plo64) phi64 = plo64;
         const int plo = (int)plo64, phi = (int)phi64;
-        const char* __restrict__ xb = reinterpret_cast<const char*>(x + lo_al);
-        for (int p0 = (threadIdx.x & ~63); p0 < pairs; p0 += PFB_THREADS) {
+        // scalar loop counter and LDS base (w is wave-uniform), one 64-bit pointer per lane bumped by a constant
+        const char* __restrict__ gp = reinterpret_cast<const char*>(x + lo_al) + 16u * (unsigned)(64 * w + lane);
+        for (int p0 = 64 * w; p0 < pairs; p0 += PFB_THREADS, gp += 16 * PFB_THREADS) {
             const int p = p0 + lane;
             if (p >= plo && p < phi)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xb + (unsigned)(16 * p)),
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
                                                  (__attribute__((address_space(3))) void*)(lds + 2 * p0), 16, 0, SDR_GLDS_AUX);
         }
         if (lo_al < 0 || lo_al + 2LL * pairs > Q.n) {   // uniform: only edge tiles have guarded chunks
@@ -260,20 +261,21 @@ __global__ void __launch_bounds__(PFB_THREADS) k_pfb(PfbParams Q)
     }
     // threshold_ff over the lane's 16 outputs as an adder's carry chain (see slice_tile_hk in frontend_mfma.h):
     // bit i of H / K = output i sets / clears the state; outputs past the row's end carry no event (uniform mask)
+    // (masks built from the last output to the first: the compare's lane bit enters as the carry of mask + mask,
+    // two instructions per output and mask; "not above hi" is applied to the finished K)
     unsigned H = 0, K = 0;
 #pragma unroll
-    for (int i = 0; i < PFB_TM; ++i) {
+    for (int i = PFB_TM - 1; i >= 0; --i) {
         const float v = Q.gain * __builtin_fmaf(ar[i], ar[i], ai[i] * ai[i]);
         ar[i] = v;
-        const bool up = v > Q.hi;
-        H |= (unsigned)up << i;
-        K |= (unsigned)(!up && v < Q.lo) << i;
+        asm("v_cmp_lt_f32_e32 vcc, %1, %2\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(H) : "s"(Q.hi), "v"(v) : "vcc");
+        asm("v_cmp_gt_f32_e32 vcc, %1, %2\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(K) : "s"(Q.lo), "v"(v) : "vcc");
     }
     {
         const long long left = Q.nout - o_w;
         const unsigned vm = left >= PFB_TM ? 0xffffu : (left <= 0 ? 0u : ((1u << (int)left) - 1u));
         H &= vm;
-        K &= vm;
+        K &= vm & ~H;
     }
     const unsigned E = H | K;
     const int first = E ? __builtin_ctz(E) : -1;
@@ -312,8 +314,7 @@ __global__ void __launch_bounds__(PFB_THREADS) k_pfb(PfbParams Q)
             unsigned* pw = reinterpret_cast<unsigned*>(&pk);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const unsigned nib = (states >> (4 * k)) & 0xfu;
-                pw[k] = (nib & 1u) | ((nib & 2u) << 7) | ((nib & 4u) << 14) | ((nib & 8u) << 21);
+                pw[k] = (((states >> (4 * k)) & 0xfu) * 0x00204081u) & 0x01010101u;   // bit j of the nibble -> bit 8j
             }
             *reinterpret_cast<uint4*>(brow + o_w) = pk;
         } else {
