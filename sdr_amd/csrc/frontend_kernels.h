@@ -215,12 +215,23 @@ __device__ __forceinline__ void frontend_tile(const FrontParams& P, const FrontK
             // serialises the staging (seen: 0.46 -> 1.24 ms).  The DMA loop holds no
             // other memory operation.
             lsh = odd;
-            for (int p0 = (threadIdx.x & ~63); p0 < pairs; p0 += T) {
+            // chunk p holds samples lo_al + 2p, +1: inside the capture for p in [plo, phi) -- uniform 32-bit bounds;
+            // the loop counter and the LDS base of every DMA (M0) are scalars (the wave's first chunk read with
+            // readfirstlane), a lane keeps one 64-bit pointer and bumps it: 4 vector instructions per DMA where
+            // the per-lane 64-bit index arithmetic took 12 (25 DMAs per lane and tile at D = 50)
+            long long plo64 = lo_al < 0 ? (1 - lo_al) >> 1 : 0, phi64 = (P.n - lo_al) >> 1;
+            if (plo64 > pairs) plo64 = pairs;
+            if (phi64 > pairs) phi64 = pairs;
+            if (phi64 < plo64) phi64 = plo64;
+            const int plo = (int)plo64, phi = (int)phi64;
+            const int wb = __builtin_amdgcn_readfirstlane((int)(threadIdx.x & ~63u));
+            const char* __restrict__ gp = reinterpret_cast<const char*>(x + lo_al) + 16u * (unsigned)(wb + lane_id());
+            const unsigned gstep = 16u * (unsigned)T;
+            for (int p0 = wb; p0 < pairs; p0 += T, gp += gstep) {
                 const int p = p0 + lane_id();
-                const long long s = lo_al + 2LL * p;
-                if (p < pairs && s >= 0 && s + 2 <= P.n)
+                if (p >= plo && p < phi)
                     __builtin_amdgcn_global_load_lds(
-                        (const __attribute__((address_space(1))) void*)(x + s),
+                        (const __attribute__((address_space(1))) void*)gp,
                         (__attribute__((address_space(3))) void*)(lds + 2 * p0), 16, 0, SDR_GLDS_AUX);
             }
             if (lo_al < 0 || lo_al + 2LL * pairs > P.n) {   // uniform: only edge tiles have guarded chunks
