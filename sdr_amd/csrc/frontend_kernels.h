@@ -227,7 +227,16 @@ __device__ __forceinline__ void frontend_tile(const FrontParams& P, const FrontK
             const int wb = __builtin_amdgcn_readfirstlane((int)(threadIdx.x & ~63u));
             const char* __restrict__ gp = reinterpret_cast<const char*>(x + lo_al) + 16u * (unsigned)(wb + lane_id());
             const unsigned gstep = 16u * (unsigned)T;
-            for (int p0 = wb; p0 < pairs; p0 += T, gp += gstep) {
+            int p0 = wb;
+            if (plo == 0 && phi == pairs) {
+                // interior tile (uniform): whole waves of chunks without a lane mask -- M0, the DMA, one pointer
+                // bump and the scalar loop; the ragged last chunk falls through to the masked loop
+                for (; p0 + 64 <= pairs; p0 += T, gp += gstep)
+                    __builtin_amdgcn_global_load_lds(
+                        (const __attribute__((address_space(1))) void*)gp,
+                        (__attribute__((address_space(3))) void*)(lds + 2 * p0), 16, 0, SDR_GLDS_AUX);
+            }
+            for (; p0 < pairs; p0 += T, gp += gstep) {
                 const int p = p0 + lane_id();
                 if (p >= plo && p < phi)
                     __builtin_amdgcn_global_load_lds(
@@ -561,13 +570,30 @@ __global__ void __launch_bounds__(256) k_frontend_raw8(FrontParams P, FrontKTaps
     uchar2* lds2 = reinterpret_cast<uchar2*>(smem_raw);
 
     // chunks wholly inside the capture: DMA, nothing else in the loop
-    for (int c0 = (t & ~63); c0 < nch; c0 += T) {
-        const int c = c0 + lane_id();
-        const long long s = lo + 8LL * c;
-        if (c < nch && s >= 0 && s + 8 <= P.n)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xb + s),
-                                             (__attribute__((address_space(3))) void*)(smem_raw + 16 * c0), 16, 0,
-                                             SDR_GLDS_AUX);
+    // (chunk c holds samples lo + 8c .. +7: inside the capture for c in [clo, chi); scalar counters, one bumped
+    // pointer per lane, no lane mask on whole waves of an interior tile -- as k_frontend)
+    {
+        long long clo64 = lo < 0 ? (7 - lo) >> 3 : 0, chi64 = (P.n - lo) >> 3;
+        if (clo64 > nch) clo64 = nch;
+        if (chi64 > nch) chi64 = nch;
+        if (chi64 < clo64) chi64 = clo64;
+        const int clo = (int)clo64, chi = (int)chi64;
+        const int wb = __builtin_amdgcn_readfirstlane(t & ~63);
+        const char* __restrict__ gp = reinterpret_cast<const char*>(xb + lo) + 16u * (unsigned)(wb + lane_id());
+        const unsigned gstep = 16u * (unsigned)T;
+        int c0 = wb;
+        if (clo == 0 && chi == nch)
+            for (; c0 + 64 <= nch; c0 += T, gp += gstep)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
+                                                 (__attribute__((address_space(3))) void*)(smem_raw + 16 * c0), 16, 0,
+                                                 SDR_GLDS_AUX);
+        for (; c0 < nch; c0 += T, gp += gstep) {
+            const int c = c0 + lane_id();
+            if (c >= clo && c < chi)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
+                                                 (__attribute__((address_space(3))) void*)(smem_raw + 16 * c0), 16, 0,
+                                                 SDR_GLDS_AUX);
+        }
     }
     const bool edge = lo < 0 || lo + 8LL * nch > P.n;                      // uniform
     if (edge) {

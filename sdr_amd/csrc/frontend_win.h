@@ -266,7 +266,13 @@ __device__ __forceinline__ void win_tile(const FrontParams& P, const int tile, c
         const int wb = __builtin_amdgcn_readfirstlane(t & ~63);
         const char* __restrict__ gp = reinterpret_cast<const char*>(x + lo_al) + 16u * (unsigned)(wb + lane);
         const unsigned gstep = 16u * (unsigned)T;
-        for (int p0 = wb; p0 < pairs; p0 += T, gp += gstep) {
+        int p0 = wb;
+        if (plo == 0 && phi == pairs)   // interior tile (uniform): whole waves of chunks need no lane mask
+            for (; p0 + 64 <= pairs; p0 += T, gp += gstep)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
+                                                 (__attribute__((address_space(3))) void*)(lds + 2 * p0), 16, 0,
+                                                 SDR_GLDS_AUX);
+        for (; p0 < pairs; p0 += T, gp += gstep) {
             const int p = p0 + lane;
             if (p >= plo && p < phi)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,

@@ -113,7 +113,12 @@ __global__ void __launch_bounds__(PFB_THREADS) k_pfb(PfbParams Q)
         const int plo = (int)plo64, phi = (int)phi64;
         // scalar loop counter and LDS base (w is wave-uniform), one 64-bit pointer per lane bumped by a constant
         const char* __restrict__ gp = reinterpret_cast<const char*>(x + lo_al) + 16u * (unsigned)(64 * w + lane);
-        for (int p0 = 64 * w; p0 < pairs; p0 += PFB_THREADS, gp += 16 * PFB_THREADS) {
+        int p0 = 64 * w;
+        if (plo == 0 && phi == pairs)   // interior tile (uniform): whole waves of chunks need no lane mask
+            for (; p0 + 64 <= pairs; p0 += PFB_THREADS, gp += 16 * PFB_THREADS)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
+                                                 (__attribute__((address_space(3))) void*)(lds + 2 * p0), 16, 0, SDR_GLDS_AUX);
+        for (; p0 < pairs; p0 += PFB_THREADS, gp += 16 * PFB_THREADS) {
             const int p = p0 + lane;
             if (p >= plo && p < phi)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
