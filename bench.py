@@ -927,7 +927,7 @@ def long_capture_frames_workload(torch, dist, dev, rank, world, ncat=256, steps=
     return out
 
 
-PMC_FILE = "r03_d_pmc.json"   # the committed FETCH_SIZE / WRITE_SIZE passes of the current kernels (tools/profile_round.sh)
+PMC_FILE = "r03_e_pmc.json"   # the committed FETCH_SIZE / WRITE_SIZE passes of the current kernels (tools/profile_round.sh)
 
 
 def progress(msg):
