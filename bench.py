@@ -216,6 +216,7 @@ def fm_workload(torch, dev, skip_cpu, n=1 << 26, fs=2.4e6, steps=10):
     st = torch.cuda.Stream(device=dev)            # a real stream handle (the default stream's is 0 = "the chain's own")
     r.set_stream(st.cuda_stream)
     torch.cuda.synchronize()
+    prewarm(torch, lambda: r.process(x))
     for _ in range(2):
         na = r.process(x)
     torch.cuda.synchronize()
@@ -306,6 +307,7 @@ def r_shape_workload(torch, dev, skip_cpu, ncap=64, n=1 << 19, fs=2e6, steps=20)
     c = chain.Chain(fs, decim=1, taps=taps, keep_n=100, decoder=chain.DEC_TS33C, max_batch=ncap, max_frames=4,
                     max_samples=n)
     c.set_stream(torch.cuda.current_stream().cuda_stream)
+    prewarm(torch, lambda: c.batch_process(iq))
     for _ in range(3):
         c.batch_process(iq)
     torch.cuda.synchronize()
@@ -370,6 +372,7 @@ def cu8_workload(torch, dev, iq, pkts, taps, steps=20):
     c = chain.Chain(FS, decim=DECIM, center_freq=F_OFF, taps=taps, decoder=chain.DEC_TS33C, max_batch=ncap,
                     max_frames=4, max_samples=n, input_format="cu8")
     c.set_stream(torch.cuda.current_stream().cuda_stream)
+    prewarm(torch, lambda: c.batch_process(u8))
     for _ in range(3):
         c.batch_process(u8)
     torch.cuda.synchronize()
@@ -438,6 +441,7 @@ def tfa_fsk_workload(torch, dev, skip_cpu, ncap=64, n=1 << 20, fs=2e6, dev_hz=60
     c = chain.Chain(fs, decim=1, taps=taps, demod=chain.DEMOD_QUAD, demod_gain=gain, thr=(-0.2, 0.2),
                     decoder=chain.DEC_TFA_GRC, max_batch=ncap, max_frames=32, max_samples=n)
     c.set_stream(torch.cuda.current_stream().cuda_stream)
+    prewarm(torch, lambda: c.batch_process(iq))
     for _ in range(3):
         c.batch_process(iq)
     torch.cuda.synchronize()
@@ -553,6 +557,7 @@ def mixed_emitters_workload(torch, dev, skip_cpu, ncap=1250, n=N_PER_CAPTURE, fs
             if collect is not None:
                 collect[d] = c.fetch_frames()
 
+    prewarm(torch, step)
     for _ in range(2):
         step()
     torch.cuda.synchronize()
@@ -682,6 +687,7 @@ def pfb_workload(torch, dev, skip_cpu, n=1 << 26, fs=20e6, steps=10):
             for k, d in enumerate(rules):
                 collect[d] = c.fetch_frames_multi(k)
 
+    prewarm(torch, step)
     for _ in range(3):
         step()
     torch.cuda.synchronize()
@@ -930,6 +936,25 @@ def long_capture_frames_workload(torch, dist, dev, rank, world, ncat=256, steps=
 PMC_FILE = "r03_e_pmc.json"   # the committed FETCH_SIZE / WRITE_SIZE passes of the current kernels (tools/profile_round.sh)
 
 
+PREWARM_S = float(os.environ.get("SDR_BENCH_PREWARM", "0.15"))
+
+
+def prewarm(torch, fn, seconds=None):
+    """Untimed: the workload's own step for `seconds` of wall time before its warm-up steps.  A GPU that has been idle
+    (or running the generators' small kernels) needs tens of milliseconds of load before its clocks settle; five
+    0.5-ms steps do not get there (measured on one box: 0.470 ms per headline step after 5 warm-up steps, 0.448 after
+    300 -- the latency-bound back end 0.0466 -> 0.0414 ms shows it is the clock).  SDR_BENCH_PREWARM=0 switches it off
+    (the counter passes of tools/profile_round.sh)."""
+    seconds = PREWARM_S if seconds is None else seconds
+    if seconds <= 0:
+        return
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(4):
+            fn()
+        torch.cuda.synchronize()
+
+
 def progress(msg):
     """one line per workload on stderr: a long run (under a profiler, say) shows where it is"""
     print("[bench] " + msg, file=sys.stderr, flush=True)
@@ -942,6 +967,7 @@ def overlapped_pass(torch, c, step, steps, out, units, per=1, warm=3):
         return
     progress("  second pass, overlapped")
     c.set_overlap(True)
+    prewarm(torch, step)
     for _ in range(warm):
         step()
     torch.cuda.synchronize()
@@ -1212,6 +1238,14 @@ def main():
                 sdist.gather_frames(recs[b], cnts[b], world, all_recs[b], all_cnts[b])
                 ev_gathered[b].record(comm)
 
+    # untimed pre-warm (clocks): by wall time on one GPU; a fixed count when step() holds a collective, so that every rank
+    # calls it equally often
+    if use_dist:
+        for _ in range(300 if PREWARM_S > 0 else 0):
+            step()
+        torch.cuda.synchronize()
+    else:
+        prewarm(torch, step)
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -1291,6 +1325,8 @@ def main():
             "value": round(value, 1), "unit": "Msps", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "prewarm": ("%g s of the same step, untimed, before the warm-up steps (clock settling)" % PREWARM_S) if not use_dist
+                       else ("300 untimed steps before the warm-up steps (clock settling)" if PREWARM_S > 0 else "off"),
             "data": "synthetic (TS33C OOK/PWM frames, random payloads, carrier +100 kHz, AWGN; generated on the GPU)",
             "config": {"workload": "ook_batch_ts33c_xlating", "captures_per_gpu": ncap,
                        "samples_per_capture": N_PER_CAPTURE, "sample_rate": FS, "ntaps": int(taps.size),

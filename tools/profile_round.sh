@@ -9,6 +9,7 @@ timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p
 cp $(ls -S $(find /tmp/prof_$tag -name "*kernel_stats.csv") | head -1) $R/gpurun_out/${tag}_kernel_stats.csv
 python3 $R/tools/trace_by_grid.py $(ls -S $(find /tmp/prof_$tag -name "*kernel_trace.csv") | head -1) $R/gpurun_out/${tag}_kernel_stats_by_grid.csv
 # counter passes (the overlapped second passes run here too since round 3: DESIGN 4e), output kept
+export SDR_BENCH_PREWARM=0   # counters are per launch: no need for settled clocks, and serialised launches are slow
 echo "FETCH_SIZE pass" && timeout -s KILL 170 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pmc_f_$tag -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $R/gpurun_out/${tag}_pmc_fetch.log 2>&1
 echo "WRITE_SIZE pass" && timeout -s KILL 170 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pmc_w_$tag -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $R/gpurun_out/${tag}_pmc_write.log 2>&1
 cp $(ls -S $(find /tmp/pmc_f_$tag -name "*counter_collection.csv") | head -1) $R/gpurun_out/${tag}_pmc_fetch.csv
