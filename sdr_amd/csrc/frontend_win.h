@@ -88,7 +88,46 @@ __device__ __forceinline__ void win_epilogue(const FrontParams& P, const int til
         if (lane == 63) s_edge[wave] = make_float2(acc[R - 1].x, acc[R - 1].y);
         __syncthreads();
         if (lane == 0) pv = wave ? s_edge[wave - 1] : make_float2(0.f, 0.f);
-        if (P.quad_fast && !P.tap) {
+        if (FULL && P.quad_fast && !P.tap) {
+            // Threshold-only form on an interior tile: the classes go into the slicer's event masks directly (outputs
+            // walked from the last to the first, mask = mask + mask + class bit by one add-with-carry whose carry-in is
+            // the class's lane mask) -- no stand-in values, no second compare.  Same tests as the general form below.
+            const bool hi_up = P.q_s_hi >= 0.f, lo_up = P.q_s_lo > 0.f;
+            unsigned Hm = 0, Km = 0;
+            bool inband = false;
+#pragma unroll
+            for (int r = R - 1; r >= 0; --r) {
+                const float2 pr = r ? make_float2(acc[r - 1].x, acc[r - 1].y) : pv;
+                const float tr = __builtin_fmaf(acc[r].x, pr.x, acc[r].y * pr.y);
+                const float ti = __builtin_fmaf(acc[r].y, pr.x, -(acc[r].x * pr.y));
+                const float ch = __builtin_fmaf(ti, P.q_c_hi, -(tr * P.q_s_hi));
+                const float cl = __builtin_fmaf(ti, P.q_c_lo, -(tr * P.q_s_lo));
+                const float lim = (__builtin_fabsf(tr) + __builtin_fabsf(ti)) * P.q_band;
+                inband |= !(__builtin_fabsf(ch) > lim) || !(__builtin_fabsf(cl) > lim);
+                const unsigned long long m_up = __ballot(ti >= 0.f), m_ch = __ballot(ch > 0.f), m_cl = __ballot(cl < 0.f);
+                const unsigned long long gt_hi = hi_up ? (m_up & m_ch) : (m_up | m_ch);
+                const unsigned long long lt_lo = lo_up ? (~m_up | m_cl) : (~m_up & m_cl);
+                asm("v_addc_co_u32_e64 %0, vcc, %0, %0, %1" : "+v"(Hm) : "s"(gt_hi) : "vcc");
+                asm("v_addc_co_u32_e64 %0, vcc, %0, %0, %1" : "+v"(Km) : "s"(lt_lo) : "vcc");
+            }
+            if (__ballot(inband) != 0ull) {   // some lane of this wave has a sample inside a band: the wave's tile the exact way
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const float2 pr = r ? make_float2(acc[r - 1].x, acc[r - 1].y) : pv;
+                    const float tr = __builtin_fmaf(acc[r].x, pr.x, acc[r].y * pr.y);
+                    const float ti = __builtin_fmaf(acc[r].y, pr.x, -(acc[r].x * pr.y));
+                    v[r] = P.gain * fast_atan2f_dev(s_atan, ti, tr);
+                }
+                slice_masks_xn<R, true>(valid, v, P.lo, P.hi, Hm, Km);
+            } else {
+                const unsigned keep = valid[0] ? ~0u : ~1u;
+                Hm &= keep;
+                Km &= ~Hm & keep;
+            }
+            slice_tile_hk<R, true>(valid, Hm, Km, R * t, m_t0, P.keep_n, P.keep_c0, P.bits + (long long)cap * P.bits_stride,
+                                   P.tsum + (long long)cap * P.tiles_per_capture + tile, sh, pack);
+            return;
+        } else if (P.quad_fast && !P.tap) {
             // Threshold-only form (round 3).  The slicer needs whether gain*fast_atan2f(ti, tr) is above hi, below lo
             // or between -- the arctangent itself (~41 vector instructions: a division, two dependent table reads,
             // the octant ladder) cost as much as the 27-tap filter of the TFA chain.  fast_atan2f is within 1.6e-6 rad
