@@ -1224,6 +1224,14 @@ def main():
     kstep = [0]
 
     res_stream = torch.cuda.current_stream()   # the handle's stream: what sdr_export_frames writes is ordered on it
+    # Multi-rank runs: back end, frame export and gather all leave the main stream (sdr_set_overlap: the export is
+    # ordered on the handle's result stream), so the main stream holds front ends only -- one rank through RCCL,
+    # 20 steps: 0.470 ms per step with the export on the main stream, 0.457 this way (0.448 without any gather).
+    # SDR_BENCH_DIST_OVERLAP=0 keeps everything but the gather on one stream.
+    dist_overlap = use_dist and os.environ.get("SDR_BENCH_DIST_OVERLAP", "1") != "0"
+    if dist_overlap:
+        c.set_overlap(True)
+        res_stream = torch.cuda.ExternalStream(c.result_stream(), device=dev)
 
     def step():
         c.batch_process(iq)
@@ -1331,7 +1339,9 @@ def main():
             "config": {"workload": "ook_batch_ts33c_xlating", "captures_per_gpu": ncap,
                        "samples_per_capture": N_PER_CAPTURE, "sample_rate": FS, "ntaps": int(taps.size),
                        "decim": DECIM, "center_freq": F_OFF, "chain": "xlating_fir->mag2->threshold->slicer->ts33c_decoder",
-                       "parallelism": "captures sharded per GPU, RCCL all_gather of frame records" if world > 1 else "1 GPU"},
+                       "parallelism": "captures sharded per GPU, RCCL all_gather of frame records" if world > 1 else "1 GPU",
+                       "streams": ("front ends on the main stream; back end + frame export on the handle's result stream "
+                                   "(sdr_set_overlap); all_gather on a third") if dist_overlap else "one stream"},
             "roofline": {"bound": "hbm", "kernel": "k_frontend<true, false>", "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": traffic, "traffic_source": traffic_src, "kernel_ms": round(fk, 4), "backend_kernel_ms": round(bk, 4),
