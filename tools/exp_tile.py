@@ -12,11 +12,11 @@ for tile in sys.argv[1:]:
         os.environ.pop("SDR_TILE", None)
     else:
         os.environ["SDR_TILE"] = tile
-    c = chain.Chain(bench.FS, decim=50, center_freq=bench.F_OFF, taps=taps, decoder=chain.DEC_NONE, max_batch=ncap, max_samples=bench.N_PER_CAPTURE)
+    c = chain.Chain(bench.FS, decim=int(os.environ.get("SDR_D", "50")), center_freq=bench.F_OFF, taps=taps, decoder=chain.DEC_NONE, max_batch=ncap, max_samples=bench.N_PER_CAPTURE)
     c.profile_enable(True)
-    for _ in range(14):
+    for _ in range(150):
         c.batch_process(iq)
     f, b = c.profile_read()
-    ms = np.mean(f[2:])
+    ms = np.mean(f[-60:])
     print("tile=%s front %.4f ms  %.0f GB/s (%.1f%%)" % (tile, ms, 8.02 * ncap * bench.N_PER_CAPTURE / ms / 1e6, 8.02 * ncap * bench.N_PER_CAPTURE / ms / 1e6 / 80), flush=True)
     c.close()
