@@ -9,7 +9,7 @@ iq = torch.randn((ncap, bench.N_PER_CAPTURE, 2), device=dev, dtype=torch.float32
 full = chain.low_pass(1.0, bench.FS, 20e3, 40e3)
 for nt in (61, 1, 9, 33, 61):
     taps = np.ascontiguousarray(full[:nt])
-    c = chain.Chain(bench.FS, decim=50, center_freq=bench.F_OFF, taps=taps, decoder=chain.DEC_NONE, max_batch=ncap, max_frames=4, max_samples=bench.N_PER_CAPTURE)
+    c = chain.Chain(bench.FS, decim=int(os.environ.get("SDR_D", "50")), center_freq=bench.F_OFF, taps=taps, decoder=chain.DEC_NONE, max_batch=ncap, max_frames=4, max_samples=bench.N_PER_CAPTURE)
     c.profile_enable(True)
     for _ in range(150):
         c.batch_process(iq)
