@@ -36,6 +36,58 @@ __device__ __forceinline__ double readlane_f64(double x, int l)
     return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)lo);
 }
 
+// v[lane ^ J] through the vector ALU instead of the LDS crossbar (ds_bpermute: ~120 cycles per exchange for a lone
+// wavefront): DPP quad_perm / row_half_mirror / row_mirror for J = 1, 2, 4, 8, gfx950's v_permlane16_swap /
+// v_permlane32_swap for J = 16, 32 (tools/micro/xorlane.hip checks all six against __shfl_xor on the GPU).
+template <int CTRL>
+__device__ __forceinline__ int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }
+template <int J>
+__device__ __forceinline__ int xor_lane_i32(int v)
+{
+    if (J == 1) return dpp_i32<0xB1>(v);                      // quad_perm [1,0,3,2]
+    if (J == 2) return dpp_i32<0x4E>(v);                      // quad_perm [2,3,0,1]
+    if (J == 4) return dpp_i32<0x1B>(dpp_i32<0x141>(v));      // row_half_mirror (^7), quad_perm [3,2,1,0] (^3)
+    if (J == 8) return dpp_i32<0x141>(dpp_i32<0x140>(v));     // row_mirror (^15), row_half_mirror (^7)
+    const int lane = threadIdx.x & 63;
+    if (J == 16) {
+        const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+        return (lane & 16) ? r[0] : r[1];
+    }
+    const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    return (lane & 32) ? r[0] : r[1];
+}
+template <int J>
+__device__ __forceinline__ double xor_lane_f64(double x)
+{
+    const long long b = __builtin_bit_cast(long long, x);
+    const unsigned lo = (unsigned)xor_lane_i32<J>((int)(unsigned)b);
+    const unsigned hi = (unsigned)xor_lane_i32<J>((int)(unsigned)(b >> 32));
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)lo);
+}
+// one compare-exchange round of the 128-slot bitonic network at distance J < 64 inside the merge of size K
+template <int K, int J>
+__device__ __forceinline__ void bitonic_round(double& a0, double& a1, int lane)
+{
+    const double b0 = xor_lane_f64<J>(a0), b1 = xor_lane_f64<J>(a1);
+    const bool lower = (lane & J) == 0;
+    // slot index e = lane (h = 0) or 64 + lane (h = 1): ascending iff (e & K) == 0
+    const bool asc0 = (lane & K) == 0, asc1 = ((64 + lane) & K) == 0;
+    a0 = (lower == asc0) ? fmin(a0, b0) : fmax(a0, b0);
+    a1 = (lower == asc1) ? fmin(a1, b1) : fmax(a1, b1);
+}
+template <int K, int J>
+__device__ __forceinline__ void bitonic_merge(double& a0, double& a1, int lane)
+{
+    if constexpr (J == 64) {   // partner = the lane's other slot; K == 128: ascending
+        const double lo = fmin(a0, a1), hi = fmax(a0, a1);
+        a0 = lo;
+        a1 = hi;
+    } else {
+        bitonic_round<K, J>(a0, a1, lane);
+    }
+    if constexpr (J > 1) bitonic_merge<K, J / 2>(a0, a1, lane);
+}
+
 // dst[rank] = value for every valid element; returns the number of valid ones.
 // Candidates are held one per lane and broadcast with v_readlane (uniform lane index):
 // no LDS round trip inside the O(n^2/64) loop -- the first version read every
@@ -53,22 +105,14 @@ __device__ inline int wave_rank_sort(V val, OK ok, int n, double* dst)
         const bool m0 = lane < n && ok(lane), m1 = lane + 64 < n && ok(lane + 64);
         double a0 = m0 ? val(lane) : inf, a1 = m1 ? val(lane + 64) : inf;
         const int total = __builtin_popcountll(__ballot(m0)) + __builtin_popcountll(__ballot(m1));
-        for (int k = 2; k <= 128; k <<= 1) {
-            for (int j = k >> 1; j >= 1; j >>= 1) {
-                if (j == 64) {   // partner = the lane's other slot; k == 128: ascending
-                    const double lo = fmin(a0, a1), hi = fmax(a0, a1);
-                    a0 = lo;
-                    a1 = hi;
-                } else {
-                    const double b0 = __shfl_xor(a0, j), b1 = __shfl_xor(a1, j);
-                    const bool lower = (lane & j) == 0;
-                    // slot index e = lane (h = 0) or 64 + lane (h = 1): ascending iff (e & k) == 0
-                    const bool asc0 = (lane & k) == 0, asc1 = ((64 + lane) & k) == 0;
-                    a0 = (lower == asc0) ? fmin(a0, b0) : fmax(a0, b0);
-                    a1 = (lower == asc1) ? fmin(a1, b1) : fmax(a1, b1);
-                }
-            }
-        }
+        // (round 3: the 27 exchanges between lanes by DPP / permlane instead of ds_bpermute, the rounds unrolled)
+        bitonic_merge<2, 1>(a0, a1, lane);
+        bitonic_merge<4, 2>(a0, a1, lane);
+        bitonic_merge<8, 4>(a0, a1, lane);
+        bitonic_merge<16, 8>(a0, a1, lane);
+        bitonic_merge<32, 16>(a0, a1, lane);
+        bitonic_merge<64, 32>(a0, a1, lane);
+        bitonic_merge<128, 64>(a0, a1, lane);
         if (lane < total) dst[lane] = a0;
         if (lane + 64 < total) dst[lane + 64] = a1;
         wave_sync();
