@@ -21,6 +21,10 @@
 
 #define WIN_R 10
 #define WIN_W 16
+// k_frontend_win's DM template argument: 0 = demodulator and outputs read from the parameters; SDR_DEMOD_MAG2 = mag^2
+// chains only; SDR_DEMOD_QUAD | WIN_DM_SLICE_ONLY = discriminator chains that only slice (no float output)
+#define WIN_DM_SLICE_ONLY 0x10
+#define WIN_DM_QUAD_SLICE (SDR_DEMOD_QUAD | WIN_DM_SLICE_ONLY)
 
 // LDS floats of the tap table (shifted copy + one block of slack), 16-B multiple
 __host__ __device__ inline int win_tap_floats(int ntaps, bool cplx = false) { return ((ntaps + 1 + WIN_W + 3) & ~3) * (cplx ? 2 : 1); }
@@ -43,7 +47,8 @@ __device__ __forceinline__ void win_epilogue(const FrontParams& P, const int til
 {
     constexpr int R = WIN_R;
     typedef win_v2f v2f;
-    const int demod = DM ? DM : P.demod;
+    const int demod = DM ? (DM & 3) : P.demod;
+    constexpr bool SLICE_ONLY = (DM & WIN_DM_SLICE_ONLY) != 0;   // no float tap output in this instantiation
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const long long m0 = m_t0 + (long long)R * t;
     bool valid[R];
@@ -88,7 +93,7 @@ __device__ __forceinline__ void win_epilogue(const FrontParams& P, const int til
         if (lane == 63) s_edge[wave] = make_float2(acc[R - 1].x, acc[R - 1].y);
         __syncthreads();
         if (lane == 0) pv = wave ? s_edge[wave - 1] : make_float2(0.f, 0.f);
-        if (FULL && P.quad_fast && !P.tap) {
+        if (FULL && P.quad_fast && (SLICE_ONLY || !P.tap)) {
             // Threshold-only form on an interior tile: the classes go into the slicer's event masks directly (outputs
             // walked from the last to the first, mask = mask + mask + class bit by one add-with-carry whose carry-in is
             // the class's lane mask) -- no stand-in values, no second compare.  Same tests as the general form below.
@@ -127,7 +132,7 @@ __device__ __forceinline__ void win_epilogue(const FrontParams& P, const int til
             slice_tile_hk<R, true>(valid, Hm, Km, R * t, m_t0, P.keep_n, P.keep_c0, P.bits + (long long)cap * P.bits_stride,
                                    P.tsum + (long long)cap * P.tiles_per_capture + tile, sh, pack);
             return;
-        } else if (P.quad_fast && !P.tap) {
+        } else if (P.quad_fast && (SLICE_ONLY || !P.tap)) {
             // Threshold-only form (round 3).  The slicer needs whether gain*fast_atan2f(ti, tr) is above hi, below lo
             // or between -- the arctangent itself (~41 vector instructions: a division, two dependent table reads,
             // the octant ladder) cost as much as the 27-tap filter of the TFA chain.  fast_atan2f is within 1.6e-6 rad
@@ -179,7 +184,7 @@ __device__ __forceinline__ void win_epilogue(const FrontParams& P, const int til
 #pragma unroll
         for (int r = 0; r < R; ++r) v[r] = P.gain * v[r];
     }
-    if (P.tap) {
+    if (!SLICE_ONLY && P.tap) {
         float* dst = P.tap + (long long)cap * P.tap_stride;
         if (FULL) {
             // a lane's R floats in a row are R stores at stride R floats, each touching every cache line of the
@@ -201,7 +206,7 @@ __device__ __forceinline__ void win_epilogue(const FrontParams& P, const int til
                 if (valid[r]) dst[m0 + r] = v[r];
         }
     }
-    if (!P.do_slice) return;
+    if (!SLICE_ONLY && !P.do_slice) return;
     slice_tile_xn<R, FULL>(valid, v, R * t, m_t0, P.lo, P.hi, P.keep_n, P.keep_c0, P.bits + (long long)cap * P.bits_stride,
                            P.tsum + (long long)cap * P.tiles_per_capture + tile, sh, pack);
 }
@@ -215,7 +220,7 @@ template <bool CPLX, int DM>
 __device__ __forceinline__ void win_tile(const FrontParams& P, const int tile, const int cap, unsigned char* smem_raw,
                                          int* sh, const float* s_atan, float2* s_edge)
 {
-    const int demod = DM ? DM : P.demod;
+    const int demod = DM ? (DM & 3) : P.demod;
     constexpr int R = WIN_R, W = WIN_W;
     const int T = blockDim.x, t = threadIdx.x, lane = t & 63;
     const int nt = P.ntaps, H = nt - 1;
@@ -442,13 +447,13 @@ __device__ __forceinline__ void win_tile(const FrontParams& P, const int tile, c
 // the R shape -- two buffers are 43 KB of LDS, 3 workgroups per CU instead of 7, and this kernel lives on its
 // 28 resident waves hiding each other's LDS and fma latencies, not on prefetch.)
 template <bool CPLX, int DM>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DM == SDR_DEMOD_MAG2 ? 6 : 1))) k_frontend_win(FrontParams P)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DM == SDR_DEMOD_MAG2 || DM == WIN_DM_QUAD_SLICE ? 6 : 1))) k_frontend_win(FrontParams P)
 {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     __shared__ int sh[12];
     __shared__ float s_atan[DM == SDR_DEMOD_MAG2 ? 1 : 257];
     __shared__ float2 s_edge[4];
-    if (DM != SDR_DEMOD_MAG2 && P.demod == SDR_DEMOD_QUAD)
+    if (DM != SDR_DEMOD_MAG2 && (DM == WIN_DM_QUAD_SLICE || P.demod == SDR_DEMOD_QUAD))
         for (int i = threadIdx.x; i < 257; i += blockDim.x) s_atan[i] = P.atan_tab[i];
     win_tile<CPLX, DM>(P, blockIdx.x, blockIdx.y, smem_raw, sh, s_atan, s_edge);
 }

@@ -73,6 +73,7 @@ struct sdr_handle {
     bool reuse_next = false;        // set by sdr_redecode around its launch_back
     int lvl_override = 0;           // set by sdr_process_runs around its launch_back (BackParams.lvl_override)
     long long runs_cap = 0;
+    bool no_quad_inst = false;   // env SDR_NO_QUAD_INST: discriminator chains stay on the generic k_frontend_win
     double* d_cur = nullptr;
     DecState* d_st = nullptr;
     // sdr_redecode_multi: tables for rows x decoders virtual captures
@@ -753,6 +754,7 @@ extern "C" int sdr_create(const sdr_chain_cfg* cfg, sdr_handle** out)
     if (const char* pe = getenv("SDR_PIPE")) h->pipe_mode = atoi(pe);
     if (const char* pe = getenv("SDR_TPW")) h->pipe_tpw = atoi(pe) > 0 ? atoi(pe) : 1;
     h->no_ktaps = getenv("SDR_NO_KTAPS") != nullptr;
+    h->no_quad_inst = getenv("SDR_NO_QUAD_INST") != nullptr;
     h->no_raw8 = getenv("SDR_NO_RAW8") != nullptr;
     h->no_reuse = getenv("SDR_NO_REUSE") != nullptr;
     h->no_seg = getenv("SDR_NO_SEG") != nullptr;
@@ -1229,6 +1231,8 @@ static int launch_front(sdr_handle* h, const float2* x, long long stride, long l
     else if (g.win)
         if (P.demod == SDR_DEMOD_MAG2)
             hipLaunchKernelGGL((k_frontend_win<false, SDR_DEMOD_MAG2>), grid, block, g.lds, h->stream, P);
+        else if (P.demod == SDR_DEMOD_QUAD && P.do_slice && !P.tap && !h->no_quad_inst)
+            hipLaunchKernelGGL((k_frontend_win<false, WIN_DM_QUAD_SLICE>), grid, block, g.lds, h->stream, P);
         else
             hipLaunchKernelGGL((k_frontend_win<false, 0>), grid, block, g.lds, h->stream, P);
     else if (g.mfma && g.mfma2) {
