@@ -513,7 +513,8 @@ __global__ void __launch_bounds__(256) k_frontend(FrontParams P, FrontKTaps KT)
 // Tap loop of k_frontend_raw8: samples are (I, Q) byte pairs in LDS, converted as they are read.
 template <bool CPLX>
 __device__ __forceinline__ void raw8_fir(const FrontKTaps& KT, const unsigned short* pu, const int nt, const bool edge,
-                                         const long long s0, const long long vlo, const long long n, float& ar, float& ai)
+                                         const bool even_d, const bool lead_odd, const long long s0, const long long vlo, const long long n,
+                                         float& ar, float& ai)
 {
     const float kS = 0.0078125f, kC = -127.4f * 0.0078125f;
     auto mac = [&](unsigned r, bool ok, int j) {
@@ -527,7 +528,28 @@ __device__ __forceinline__ void raw8_fir(const FrontKTaps& KT, const unsigned sh
         if (CPLX) ai = __builtin_fmaf(b, sx, ai);
     };
     int j = 0;
-    if (!edge) {
+    if (!edge && even_d) {
+        // Even decimation: every lane's window starts at the same parity, so after one single tap when that parity is
+        // odd the window is read as DWORDS (two samples each, 4-byte aligned: ds_read2_b32 at full LDS rate).  Read as
+        // 16-bit items the compiler merged eight of them into one ds_read_b128 at a 4-byte-aligned address (lane
+        // stride 2*D bytes), which the LDS serves at a third of its rate: 24 cycles per instruction by
+        // SQ_LDS_IDX_ACTIVE, the LDS as busy as the vector ALUs (profiles/r03_i_raw8_sq.csv).
+        if (lead_odd) {   // uniform: LDS sample index of tap 0 = off + t*D, D even
+            mac(pu[0], true, 0);
+            j = 1;
+        }
+        for (; j + 8 <= nt; j += 8) {
+            const unsigned* pw = reinterpret_cast<const unsigned*>(pu + j);
+            unsigned w[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) w[u] = pw[u];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                mac(w[u] & 0xffffu, true, j + 2 * u);
+                mac(w[u] >> 16, true, j + 2 * u + 1);
+            }
+        }
+    } else if (!edge) {
         for (; j + 8 <= nt; j += 8) {
             unsigned r[8];
 #pragma unroll
@@ -620,9 +642,9 @@ __global__ void __launch_bounds__(256) k_frontend_raw8(FrontParams P, FrontKTaps
         const unsigned short* pu = reinterpret_cast<const unsigned short*>(smem_raw) + off + t * P.D;
         const long long s0 = lo_idx + (long long)t * P.D;                  // sample index of tap 0
         if (P.taps_complex)
-            raw8_fir<true>(KT, pu, P.ntaps, edge, s0, vlo, P.n, ar, ai);
+            raw8_fir<true>(KT, pu, P.ntaps, edge, !(P.D & 1), (off & 1) != 0, s0, vlo, P.n, ar, ai);
         else
-            raw8_fir<false>(KT, pu, P.ntaps, edge, s0, vlo, P.n, ar, ai);
+            raw8_fir<false>(KT, pu, P.ntaps, edge, !(P.D & 1), (off & 1) != 0, s0, vlo, P.n, ar, ai);
         if (!have_y) ar = ai = 0.f;
     }
     if (have_y && P.nco_tab) {
