@@ -317,7 +317,7 @@ def r_shape_workload(torch, dev, skip_cpu, ncap=64, n=1 << 19, fs=2e6, steps=20)
     for _ in range(3):
         c.batch_process(iq)
     torch.cuda.synchronize()
-    c.profile_enable(True)
+    c.profile_enable(True, PROFILE_EVERY)
     t0 = time.perf_counter()
     for _ in range(steps):
         c.batch_process(iq)
@@ -382,7 +382,7 @@ def cu8_workload(torch, dev, iq, pkts, taps, steps=20):
     for _ in range(3):
         c.batch_process(u8)
     torch.cuda.synchronize()
-    c.profile_enable(True)
+    c.profile_enable(True, PROFILE_EVERY)
     t0 = time.perf_counter()
     for _ in range(steps):
         c.batch_process(u8)
@@ -451,7 +451,7 @@ def tfa_fsk_workload(torch, dev, skip_cpu, ncap=64, n=1 << 20, fs=2e6, dev_hz=60
     for _ in range(3):
         c.batch_process(iq)
     torch.cuda.synchronize()
-    c.profile_enable(True)
+    c.profile_enable(True, PROFILE_EVERY)
     t0 = time.perf_counter()
     for _ in range(steps):
         c.batch_process(iq)
@@ -567,7 +567,7 @@ def mixed_emitters_workload(torch, dev, skip_cpu, ncap=1250, n=N_PER_CAPTURE, fs
     for _ in range(2):
         step()
     torch.cuda.synchronize()
-    c.profile_enable(True)
+    c.profile_enable(True, PROFILE_EVERY)
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
@@ -697,7 +697,7 @@ def pfb_workload(torch, dev, skip_cpu, n=1 << 26, fs=20e6, steps=10):
     for _ in range(3):
         step()
     torch.cuda.synchronize()
-    c.profile_enable(True)
+    c.profile_enable(True, PROFILE_EVERY)
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
@@ -943,6 +943,10 @@ PMC_FILE = "r03_j_pmc.json"   # the committed FETCH_SIZE / WRITE_SIZE passes of 
 
 
 PREWARM_S = float(os.environ.get("SDR_BENCH_PREWARM", "0.15"))
+# kernel durations inside the timed region come from HIP events around every PROFILE_EVERY-th processing call of a handle
+# (its sdr_redecode* calls are timed with it): an event is a packet of its own on the queue, three per call were 10 us
+# of the 0.44-ms headline step (tools/exp_prof_cost.py)
+PROFILE_EVERY = int(os.environ.get("SDR_BENCH_PROFILE_EVERY", "3"))
 
 
 def prewarm(torch, fn, seconds=None):
@@ -977,7 +981,7 @@ def overlapped_pass(torch, c, step, steps, out, units, per=1, warm=3):
     for _ in range(warm):
         step()
     torch.cuda.synchronize()
-    c.profile_enable(True)
+    c.profile_enable(True, PROFILE_EVERY)
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
@@ -1266,7 +1270,7 @@ def main():
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
-    c.profile_enable(True)
+    c.profile_enable(True, PROFILE_EVERY)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -1351,7 +1355,8 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_frontend<true, false>", "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": traffic, "traffic_source": traffic_src, "kernel_ms": round(fk, 4), "backend_kernel_ms": round(bk, 4),
-                         "bytes_per_launch": BYTES_PER_SAMPLE * samples_per_step},
+                         "bytes_per_launch": BYTES_PER_SAMPLE * samples_per_step,
+                         "kernel_timing": "HIP events on the handle's stream around every %d%s step of the timed region" % (PROFILE_EVERY, "rd" if PROFILE_EVERY == 3 else "th")},
             "frames_decoded": len(frames) * world, "verified": "all captures decode to the transmitted packets; 3 captures bit-exact vs oracle",
         }
         if shared_gpu:

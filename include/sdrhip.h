@@ -287,6 +287,8 @@ SDR_API int sdr_timer_elapsed_ms(sdr_handle* h, float* ms);
 /* Per-launch kernel timing: when enabled, every call brackets its front-end
  * (filter+demod+slice) and back-end (run-length+decode) launches with HIP
  * events on the handle's stream (ring of 256 calls, no host sync).
+ * on = N > 1 times every N-th call only (a timing event is a packet of its own
+ * on the queue, ~3 us: three per call cost 10 us of a 0.44-ms step).
  * sdr_profile_read synchronises and returns the last n<=cap durations. */
 SDR_API int sdr_profile_enable(sdr_handle* h, int on);
 SDR_API int sdr_profile_read(sdr_handle* h, float* front_ms, float* back_ms, int cap, int* n);

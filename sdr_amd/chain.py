@@ -382,8 +382,9 @@ class Chain(object):
         """run table of the last decoding call: runs + 1 positions (empty if it decoded nothing)"""
         return self._fetch_array(self._L.sdr_fetch_runs, np.int32, int(row))
 
-    def profile_enable(self, on=True):
-        _lib.check(self._h, self._L.sdr_profile_enable(self._h, int(on)))
+    def profile_enable(self, on=True, every=1):
+        """HIP-event timing of the front-end / back-end launches: of every call, or of every `every`-th one."""
+        _lib.check(self._h, self._L.sdr_profile_enable(self._h, int(every) if on else 0))
 
     def profile_read(self):
         """-> (front_ms[], back_ms[]) HIP-event durations of the last <=256 calls."""

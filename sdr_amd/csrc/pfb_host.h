@@ -158,7 +158,7 @@ static int pfb_batch(sdr_handle* h, const void* iq, size_t n, size_t stride, int
     }
     CallGeom g;
     pfb_geom(h, (long long)(n / M), 0, c.keep_n - 1, g);
-    if (h->profile) HIPCHK(h, hipEventRecord(h->pev[3 * (h->pcount % SDR_PROF_RING)], h->stream));
+    if (prof_begin(h)) HIPCHK(h, hipEventRecord(h->pev[3 * (h->pcount % SDR_PROF_RING)], h->stream));
     int r = pfb_launch(h, x, (long long)stride, (long long)n, ncap, g, nullptr, 0, 0);
     if (r) return r;
     int run = 1;
@@ -207,7 +207,7 @@ static int pfb_stream(sdr_handle* h, const void* iq, size_t n, int is_dev, sdr_o
         run = 1;
     const long long off = is_stream_decoder(c.decoder) ? h->raw_n : 0;
     const long long nb_total = off == 0 ? g.ne : total;
-    if (h->profile) HIPCHK(h, hipEventRecord(h->pev[3 * (h->pcount % SDR_PROF_RING)], h->stream));
+    if (prof_begin(h)) HIPCHK(h, hipEventRecord(h->pev[3 * (h->pcount % SDR_PROF_RING)], h->stream));
     int r = pfb_launch(h, x, 0, (long long)n, 1, g, hist_ptr(h), hist_valid(h), off);
     if (r) return r;
     r = launch_back(h, M, g, off, nb_total, 0, 1, run);

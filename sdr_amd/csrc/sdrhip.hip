@@ -137,7 +137,9 @@ struct sdr_handle {
     double dec_rate = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // per-launch profiling ring
-    bool profile = false;
+    bool profile = false;        // events are recorded in the call in progress (decided by prof_begin)
+    int prof_every = 0;          // sdr_profile_enable(h, N): every N-th call is timed; 0 = off
+    unsigned long long prof_calls = 0;
     std::vector<hipEvent_t> pev;   // 3 events per slot: front start, front end/back start, back end
     unsigned long long pcount = 0;
 
@@ -149,6 +151,7 @@ struct sdr_handle {
     hipStream_t bstream = nullptr;
     bool ov_call = false;        // the current call puts its back-end side on bstream
     bool ov_pending = false;     // bstream holds work h->stream has not been ordered behind
+    bool ov_front_covered = false;   // bstream already waits for everything the library has queued on h->stream
     int ov_sel = 0, ov_last = 0; // pair the last batch wrote; pair whose event was recorded last
     int8_t* d_bits2 = nullptr;
     TileSum* d_tsum2 = nullptr;
@@ -236,6 +239,7 @@ static int ov_join(sdr_handle* h)
         HIPCHK(h, hipStreamWaitEvent(h->stream, h->ov_back[h->ov_last], 0));
         h->ov_pending = false;
     }
+    if (h) h->ov_front_covered = false;   // the caller is about to queue work on h->stream outside an overlapped call
     return SDR_OK;
 }
 #define OV_JOIN(h)              \
@@ -243,6 +247,15 @@ static int ov_join(sdr_handle* h)
         int j_ = ov_join(h);    \
         if (j_) return j_;      \
     } while (0)
+
+// first event of a processing call's triple: decides whether THIS call -- and the sdr_redecode* calls behind it, which
+// keep the decision -- is timed (every prof_every-th one).  A timing event is a packet of its own on the queue, ~3 us
+// each: three per step were 10 us of the 0.44-ms headline step
+static inline bool prof_begin(sdr_handle* h)
+{
+    h->profile = h->prof_every > 0 && (h->prof_calls++ % (unsigned long long)h->prof_every) == 0;
+    return h->profile;
+}
 
 struct OvScope {   // marks the calls whose back-end side goes to the result stream
     sdr_handle* h;
@@ -253,13 +266,21 @@ struct OvScope {   // marks the calls whose back-end side goes to the result str
 
 // the stream the back-end side of this call runs on; inside an overlapped call it is ordered behind
 // everything queued on h->stream so far (the front end just launched)
-static int result_stream_begin(sdr_handle* h, hipStream_t* bs)
+// user_bufs: the call writes buffers of the caller (sdr_export_*), whose earlier uses are ordered on h->stream -- always
+// order behind it.  A call that touches the handle's own tables only (back end, sdr_redecode*) needs the wait once
+// per front end: a second event record + cross-queue wait per step is a barrier packet the result queue sits
+// behind for ~20 us although its dependency is long satisfied (kernel timeline of the channelizer workload:
+// 26 us idle in front of the sdr_redecode_multi launch of every step).
+static int result_stream_begin(sdr_handle* h, hipStream_t* bs, bool user_bufs = false)
 {
     *bs = h->stream;
     if (!h->ov_call) return SDR_OK;
-    OV_TRACE("[ov %p] begin: record front on stream, bstream waits front\n", (void*)h);
-    HIPCHK(h, hipEventRecord(h->ov_front, h->stream));
-    HIPCHK(h, hipStreamWaitEvent(h->bstream, h->ov_front, 0));
+    if (user_bufs || !h->ov_front_covered) {
+        OV_TRACE("[ov %p] begin: record front on stream, bstream waits front\n", (void*)h);
+        HIPCHK(h, hipEventRecord(h->ov_front, h->stream));
+        HIPCHK(h, hipStreamWaitEvent(h->bstream, h->ov_front, 0));
+        h->ov_front_covered = true;
+    }
     *bs = h->bstream;
     return SDR_OK;
 }
@@ -279,6 +300,7 @@ static int ov_next_buffers(sdr_handle* h)
     std::swap(h->d_bits, h->d_bits2);
     std::swap(h->d_tsum, h->d_tsum2);
     h->ov_sel ^= 1;
+    h->ov_front_covered = false;   // a front end is about to be queued on h->stream
     OV_TRACE("[ov %p] next buffers: pair %d%s\n", (void*)h, h->ov_sel, h->ov_back_rec[h->ov_sel] ? ", stream waits its back event" : "");
     if (h->ov_back_rec[h->ov_sel]) HIPCHK(h, hipStreamWaitEvent(h->stream, h->ov_back[h->ov_sel], 0));
     return SDR_OK;
@@ -977,6 +999,7 @@ extern "C" int sdr_set_stream(sdr_handle* h, void* s)
 {
     if (!h) return SDR_E_ARG;
     h->stream = s ? (hipStream_t)s : h->own_stream;
+    h->ov_front_covered = false;
     if (h->pre) h->pre->stream = h->stream;
     return SDR_OK;
 }
@@ -1337,7 +1360,7 @@ static int launch_front_and_back(sdr_handle* h, const float2* x, long long strid
     if (post && (int)h->post_taps.size() != c.post_ntaps)
         return fail(h, SDR_E_ARG, "post-demod filter configured but sdr_set_post_taps not called");
     if (g.tiles > h->tsum_stride) return fail(h, SDR_E_CAPACITY, "tile table too small");
-    if (h->profile) HIPCHK(h, hipEventRecord(h->pev[3 * (h->pcount % SDR_PROF_RING)], h->stream));
+    if (prof_begin(h)) HIPCHK(h, hipEventRecord(h->pev[3 * (h->pcount % SDR_PROF_RING)], h->stream));
     if (g.nout > 0 && !h->squelch_on) {
         int r = launch_front(h, x, stride, n, ncap, hist, hist_len, g, patch_off, false);
         if (r) return r;
@@ -1950,7 +1973,9 @@ extern "C" int sdr_profile_enable(sdr_handle* h, int on)
         h->pev.resize(3 * SDR_PROF_RING);
         for (auto& e : h->pev) HIPCHK(h, hipEventCreate(&e));
     }
-    h->profile = on != 0;
+    h->prof_every = on > 0 ? on : 0;
+    h->prof_calls = 0;
+    h->profile = false;
     h->pcount = 0;
     return SDR_OK;
 }
@@ -2007,7 +2032,7 @@ extern "C" int sdr_export_frames(sdr_handle* h, void* frames_dev, size_t frames_
     OvScope ovs(h, h->overlap);
     hipStream_t bs;
     {
-        int rb = result_stream_begin(h, &bs);
+        int rb = result_stream_begin(h, &bs, true);
         if (rb) return rb;
     }
     hipLaunchKernelGGL(k_export_frames, dim3(blocks), dim3(256), 0, bs, h->d_frames, h->d_st, B,
@@ -2204,7 +2229,7 @@ extern "C" int sdr_batch_process_bits(sdr_handle* h, const int8_t* bits, size_t 
     int run = 1;
     if (is_stream_decoder(h->cfg.decoder))
         run = ((double)g.ne * 1e6 / h->dec_rate > decoder_reset_limit(h->cfg.decoder)) ? 1 : 0;
-    if (h->profile) HIPCHK(h, hipEventRecord(h->pev[3 * (h->pcount % SDR_PROF_RING)], h->stream));
+    if (prof_begin(h)) HIPCHK(h, hipEventRecord(h->pev[3 * (h->pcount % SDR_PROF_RING)], h->stream));
     int r = launch_back(h, rows, g, 0, g.ne, 1, 0, run);
     if (r) return r;
     h->last_ncap = rows;
@@ -2227,7 +2252,7 @@ extern "C" int sdr_export_bits(sdr_handle* h, void* bits_dev, size_t cap_bytes, 
     OvScope ovs(h, h->overlap);   // as sdr_export_frames
     hipStream_t bs;
     {
-        int rb = result_stream_begin(h, &bs);
+        int rb = result_stream_begin(h, &bs, true);
         if (rb) return rb;
     }
     if (rows == 1 || (size_t)h->bits_stride == width) {
@@ -2484,9 +2509,9 @@ extern "C" int sdr_batch_process_static(sdr_handle* h, const void* iq_dev, size_
     // run the handle's own launch path on the static tables
     struct Saved {
         int8_t* bits; long long bstride; TileSum* tsum; int tstride; int32_t *runs, *runs_seg, *runs_n; long long rcap;
-        double* cur; DecState* st; sdr_frame* frames; unsigned long long out_count; bool profile;
+        double* cur; DecState* st; sdr_frame* frames; unsigned long long out_count; int prof_every;
     } sv{h->d_bits, h->bits_stride, h->d_tsum, h->tsum_stride, h->d_runs, h->d_runs_seg, h->d_runs_n, h->runs_cap,
-         h->d_cur, h->d_st, h->d_frames, h->out_count, h->profile};
+         h->d_cur, h->d_st, h->d_frames, h->out_count, h->prof_every};
     h->d_bits = reinterpret_cast<int8_t*>(base + o_bits);
     h->bits_stride = bstride;
     h->d_tsum = reinterpret_cast<TileSum*>(base + o_tsum);
@@ -2499,6 +2524,7 @@ extern "C" int sdr_batch_process_static(sdr_handle* h, const void* iq_dev, size_
     h->d_st = reinterpret_cast<DecState*>(base + o_st);
     h->d_frames = reinterpret_cast<sdr_frame*>(base + o_frames);
     h->out_count = 0;
+    h->prof_every = 0;
     h->profile = false;
     int run = 1;
     if (is_stream_decoder(c.decoder))
@@ -2519,7 +2545,7 @@ extern "C" int sdr_batch_process_static(sdr_handle* h, const void* iq_dev, size_
     }
     h->d_bits = sv.bits; h->bits_stride = sv.bstride; h->d_tsum = sv.tsum; h->tsum_stride = sv.tstride;
     h->d_runs = sv.runs; h->d_runs_seg = sv.runs_seg; h->d_runs_n = sv.runs_n; h->runs_cap = sv.rcap;
-    h->d_cur = sv.cur; h->d_st = sv.st; h->d_frames = sv.frames; h->out_count = sv.out_count; h->profile = sv.profile;
+    h->d_cur = sv.cur; h->d_st = sv.st; h->d_frames = sv.frames; h->out_count = sv.out_count; h->prof_every = sv.prof_every;
     h->runs_valid = false;   // the handle's run table does not describe what its next sdr_redecode would expect
     if (!capturing) {   // whatever was queued (also by a call that failed half way) is what the next user waits for
         if (hipEventRecord(g_scratch_ev[h->device], h->stream) == hipSuccess) {
