@@ -939,7 +939,7 @@ def long_capture_frames_workload(torch, dist, dev, rank, world, ncat=256, steps=
     return out
 
 
-PMC_FILE = "r03_j_pmc.json"   # the committed FETCH_SIZE / WRITE_SIZE passes of the current kernels (tools/profile_round.sh)
+PMC_FILE = "r03_k_pmc.json"   # the committed FETCH_SIZE / WRITE_SIZE passes of the current kernels (tools/profile_round.sh)
 
 
 PREWARM_S = float(os.environ.get("SDR_BENCH_PREWARM", "0.15"))
