@@ -175,3 +175,31 @@ def test_overlap_on_long_rows_and_the_channelizer():
                     h._seen.append([(f.capture, f.status, f.packet()) for f in h.fetch_frames_multi(k)])
         assert c._seen == ref._seen
         assert sum(len(s) for s in ref._seen) >= 6
+
+
+def test_profile_every_nth_call_and_redecode_inherits():
+    """sdr_profile_enable(h, N): every N-th processing call is timed, the sdr_redecode behind a timed call with it;
+    results do not depend on the setting."""
+    n, ncap = 1 << 17, 6
+    iq = _batch(ncap, n, FS, seed=5)
+    x = _dev(iq)
+    with _chain(ncap, n) as c:
+        c.batch_process(x)
+        want = [(f.capture, f.status, f.packet()) for f in c.fetch_frames()]
+        c.profile_enable(True, 3)
+        for k in range(9):
+            c.batch_process(x)
+            c.redecode(chain.DEC_TS33C)
+        front, back = c.profile_read()
+        # calls 0, 3, 6 are timed: a (front, back) slot each, and one slot for the redecode behind each of them
+        assert len(front) == 6 and len(back) == 6
+        assert all(v > 0 for v in front[0::2]) and all(v >= 0 for v in back)
+        assert [(f.capture, f.status, f.packet()) for f in c.fetch_frames()] == want
+        c.profile_enable(True)
+        for k in range(4):
+            c.batch_process(x)
+        front, back = c.profile_read()
+        assert len(front) == 4
+        c.profile_enable(False)
+        c.batch_process(x)
+        assert len(c.profile_read()[0]) == 0
